@@ -1,0 +1,135 @@
+"""Configure-time tables the detector kernels consume (host side).
+
+* stopping power: ``target.get_dedx(nucleus, KE)`` -- which the reference evaluates inside
+  every ODE right-hand side (solver.py:64-66, one catima call each) -- is sampled once per
+  species on the "binade" grid ``E = 2^e (1 + m/32)`` MeV.  The grid makes the device lookup
+  pure bit manipulation of the f64 (exponent + top 5 mantissa bits) with a linear
+  interpolation inside the sub-bin; relative node spacing <= 1/32.
+* pad look-up: whole-millimetre table (see ``Config``), beam pads folded to -1.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _abi
+from .beam_pads import BEAM_PADS_ARRAY
+
+
+def dedx_node_energies() -> np.ndarray:
+    """Kinetic energies (MeV) of the ``DEDX_NODES`` table nodes."""
+    e = np.arange(_abi.DEDX_EMIN, _abi.DEDX_EMAX)
+    m = np.arange(_abi.DEDX_SUB)
+    nodes = (np.ldexp(1.0, e)[:, None] * (1.0 + m[None, :] / float(_abi.DEDX_SUB))).reshape(-1)
+    return np.concatenate([nodes, [np.ldexp(1.0, _abi.DEDX_EMAX)]])
+
+
+def sample_dedx_table(target, nucleus) -> np.ndarray:
+    """``target.get_dedx(nucleus, E)`` [MeV/(g/cm^2)] at every node; non-finite or negative
+    values (outside a model's validity range) are clamped to the nearest valid node."""
+    energies = dedx_node_energies()
+    table = np.array([float(target.get_dedx(nucleus, float(e))) for e in energies], dtype=np.float64)
+    bad = ~np.isfinite(table) | (table < 0.0)
+    if np.all(bad):
+        raise ValueError(f"target.get_dedx returned no valid value for {nucleus}")
+    if np.any(bad):
+        good_idx = np.flatnonzero(~bad)
+        nearest = good_idx[np.abs(np.arange(table.size)[:, None] - good_idx[None, :]).argmin(axis=1)]
+        table = table[nearest]
+    return np.ascontiguousarray(table)
+
+
+def compact_pad_lut(pad_grid: np.ndarray, edges: np.ndarray) -> tuple[np.ndarray, int]:
+    """Whole-mm LUT equivalent to (pad_grid, edges) under the reference's position_to_index
+    (transporter.py:110-118): valid floor(x_mm) = k with low <= k < high, index
+    int((k - low) / bin).  Returns (lut int16 [n, n], k_min)."""
+    low, high, step = (float(v) for v in edges[:3])
+    k_min = int(np.ceil(low))
+    k_max = int(np.ceil(high)) - 1
+    ks = np.arange(k_min, k_max + 1, dtype=np.float64)
+    idx = ((ks - low) / step).astype(np.int64)
+    if idx.size == 0 or idx.max() >= pad_grid.shape[0] or idx.max() >= pad_grid.shape[1]:
+        raise ValueError("pad grid edges do not match the pad grid shape")
+    lut = np.ascontiguousarray(pad_grid[np.ix_(idx, idx)]).astype(np.int16)
+    return lut, k_min
+
+
+def fold_beam_pads(lut: np.ndarray) -> np.ndarray:
+    """-1 wherever the pad is one of the beam pads (the ``pad not in BEAM_PADS_ARRAY`` test of
+    transporter.py:162,237 evaluated once per LUT cell instead of once per pixel)."""
+    out = lut.copy()
+    out[np.isin(out, BEAM_PADS_ARRAY)] = -1
+    return out
+
+
+def build_det_desc(config, nuclei: list, ode_substeps: int = 1, fold_beam: bool = True):
+    """-> (DetDesc, keepalive).  ``nuclei``: species table (objects with Z, A, mass)."""
+    if config.pad_grid_edges is None or config.pad_grid is None:
+        raise ValueError("Pad grid is not loaded at generate_point_cloud!")  # solver.py:400-401
+    if len(nuclei) > _abi.MAX_SPECIES:
+        raise ValueError(f"at most {_abi.MAX_SPECIES} nuclear species per configuration")
+    det = config.det_params
+    keep: list = []
+    desc = _abi.DetDesc()
+    desc.length = float(det.length)
+    desc.efield = float(det.efield)
+    desc.bfield = float(det.bfield)
+    desc.density = float(det.gas_target.density)
+    desc.diffusion = float(det.diffusion)
+    desc.fano_factor = float(det.fano_factor)
+    desc.w_value = float(det.w_value)
+    desc.mpgd_gain = int(det.mpgd_gain)
+    desc.micromegas_edge = int(config.elec_params.micromegas_edge)
+    desc.windows_edge = int(config.elec_params.windows_edge)
+    lut, k_min = compact_pad_lut(config.pad_grid, config.pad_grid_edges)
+    if fold_beam:
+        lut = fold_beam_pads(lut)
+    lut = np.ascontiguousarray(lut)
+    keep.append(lut)
+    desc.pad_lut = lut.ctypes.data_as(C.POINTER(C.c_int16))
+    desc.lut_n = lut.shape[0]
+    desc.lut_lo = k_min
+    desc.n_species = len(nuclei)
+    desc.ode_substeps = int(ode_substeps)
+    for i, nuc in enumerate(nuclei):
+        table = sample_dedx_table(det.gas_target, nuc)
+        keep.append(table)
+        desc.species[i].Z = int(nuc.Z)
+        desc.species[i].A = int(nuc.A)
+        desc.species[i].mass = float(nuc.mass)
+        desc.species[i].dedx = _abi.dptr(table)
+    return desc, keep
+
+
+def build_layout(proton_numbers, mass_numbers, indices, species_keys: list) -> _abi.EventLayout:
+    """Which rows are simulated and which species table entry each row uses
+    (simulator.py:96-101: rows with Z == 0 are skipped)."""
+    n_rows = len(proton_numbers)
+    if n_rows > _abi.MAX_ROWS:
+        raise ValueError(f"at most {_abi.MAX_ROWS} nuclei per event")
+    if len(indices) > _abi.MAX_SIM:
+        raise ValueError(f"at most {_abi.MAX_SIM} simulated nuclei per event")
+    lay = _abi.EventLayout()
+    lay.n_rows = n_rows
+    lay.n_sim = len(indices)
+    for i in range(_abi.MAX_ROWS):
+        lay.species_of_row[i] = -1
+    for i, row in enumerate(indices):
+        row = int(row)
+        if not 0 <= row < n_rows:
+            raise IndexError(f"nucleus index {row} out of range for {n_rows} nuclei")
+        lay.indices[i] = row
+        z, a = int(proton_numbers[row]), int(mass_numbers[row])
+        if z != 0:
+            lay.species_of_row[row] = species_keys.index((z, a))
+    return lay
+
+
+def species_for(proton_numbers, mass_numbers, indices) -> list[tuple[int, int]]:
+    keys: list[tuple[int, int]] = []
+    for row in indices:
+        z, a = int(proton_numbers[int(row)]), int(mass_numbers[int(row)])
+        if z != 0 and (z, a) not in keys:
+            keys.append((z, a))
+    return keys

@@ -1,0 +1,136 @@
+"""Detector / electronics / pad-plane configuration (reference ``detector/parameters.py``).
+
+Field names, order and the ``Config`` attributes are those of the reference so user
+scripts construct them unchanged.  Differences, all host side:
+
+* the packaged pad look-up is the lossless 559x559 whole-millimetre table
+  (``tools/derive_pad_data.py``) with ``pad_grid_edges = [-280, 279, 1.0]`` -- under the
+  reference's own ``position_to_index`` (transporter.py:78-120) it returns the same pad
+  for every position as the 5600x5600 grid, at 1/100 of the memory;
+* a non-default ``pad_size_path`` is read from ``pad_size_path`` (the reference opens
+  ``geometry_path`` there, parameters.py:254-255 -- a bug not reproduced).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from importlib import resources
+from pathlib import Path
+
+import numpy as np
+
+DEFAULT = "Default"
+
+
+@dataclass
+class DetectorParams:
+    """length [m], efield [V/m], bfield [T], mpgd_gain, gas_target (``get_dedx``/``density``),
+    diffusion [V], fano_factor, w_value [eV] -- reference parameters.py:10-48."""
+
+    length: float
+    efield: float
+    bfield: float
+    mpgd_gain: int
+    gas_target: object
+    diffusion: float
+    fano_factor: float
+    w_value: float
+
+
+@dataclass
+class ElectronicsParams:
+    """clock_freq [MHz], amp_gain [lsb/fC], shaping_time [ns], micromegas_edge [tb],
+    windows_edge [tb], adc_threshold -- reference parameters.py:51-76."""
+
+    clock_freq: float
+    amp_gain: int
+    shaping_time: int
+    micromegas_edge: int
+    windows_edge: int
+    adc_threshold: int
+
+
+@dataclass
+class PadParams:
+    """Paths to the pad grid (.npz with ``grid`` and ``edges``), pad centres csv and pad sizes
+    csv; ``"Default"`` selects the packaged data -- reference parameters.py:79-94."""
+
+    grid_path: Path | str = DEFAULT
+    geometry_path: Path | str = DEFAULT
+    pad_size_path: Path | str = DEFAULT
+
+
+def _read_csv_columns(path, n_cols: int) -> np.ndarray:
+    rows = []
+    with open(path, "r") as handle:
+        handle.readline()  # header
+        for line in handle:
+            if line.strip():
+                rows.append([float(v) for v in line.split(",")[:n_cols]])
+    return np.array(rows, dtype=np.float64)
+
+
+class Config:
+    """All simulation inputs: ``det_params``, ``elec_params``, ``pad_params``, ``pad_grid``,
+    ``pad_grid_edges``, ``pad_centers``, ``pad_sizes``, ``drift_velocity`` [m / time bucket]
+    (reference parameters.py:97-162)."""
+
+    def __init__(self, detector_params: DetectorParams, electronics_params: ElectronicsParams,
+                 pad_params: PadParams):
+        self.det_params = detector_params
+        self.elec_params = electronics_params
+        self.pad_params = pad_params
+        self.pad_grid: np.ndarray | None = None
+        self.pad_grid_edges: np.ndarray | None = None
+        self.pad_centers: np.ndarray | None = None
+        self.pad_sizes: np.ndarray | None = None
+        self.drift_velocity = 0.0
+        self.calculate_drift_velocity()
+        self.load_pad_grid()
+        self.load_pad_centers()
+        self.load_pad_sizes()
+
+    def calculate_drift_velocity(self) -> None:
+        """length / (windows_edge - micromegas_edge), reference parameters.py:164-174."""
+        self.drift_velocity = self.det_params.length / float(
+            self.elec_params.windows_edge - self.elec_params.micromegas_edge
+        )
+
+    @staticmethod
+    def _packaged(name: str):
+        return resources.files("attpc_engine_amd.detector.data").joinpath(name)
+
+    def load_pad_grid(self) -> None:
+        """``pad_grid[ix, iy]`` = pad id (-1: none) for the bin whose lower edge is
+        ``edges[0] + i * edges[2]`` mm; inclusive low edge, exclusive high edge
+        (reference parameters.py:176-205)."""
+        if self.pad_params.grid_path == DEFAULT:
+            with resources.as_file(self._packaged("pad_lut_1mm.npz")) as path:
+                data = np.load(path)
+                self.pad_grid = data["grid"]
+                self.pad_grid_edges = data["edges"]
+        else:
+            data = np.load(self.pad_params.grid_path)
+            self.pad_grid = data["grid"]
+            self.pad_grid_edges = data["edges"]
+
+    def load_pad_centers(self) -> None:
+        """[10240, 2] pad centre x, y in mm (reference parameters.py:207-234)."""
+        if self.pad_params.geometry_path == DEFAULT:
+            with resources.as_file(self._packaged("pad_geometry.npz")) as path:
+                self.pad_centers = np.load(path)["centers"].copy()
+        else:
+            centers = np.zeros((10240, 2))
+            rows = _read_csv_columns(self.pad_params.geometry_path, 2)
+            centers[: len(rows)] = rows
+            self.pad_centers = centers
+
+    def load_pad_sizes(self) -> None:
+        """[10240] pad size scale (reference parameters.py:236-261)."""
+        if self.pad_params.pad_size_path == DEFAULT:
+            with resources.as_file(self._packaged("pad_geometry.npz")) as path:
+                self.pad_sizes = np.load(path)["sizes"].copy()
+        else:
+            sizes = np.zeros(10240)
+            rows = _read_csv_columns(self.pad_params.pad_size_path, 1)
+            sizes[: len(rows)] = rows[:, 0]
+            self.pad_sizes = sizes

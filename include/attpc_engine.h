@@ -1,0 +1,240 @@
+/*
+ * attpc_engine.h -- C ABI of the MI355X-native AT-TPC Monte-Carlo hot path.
+ *
+ * The reference (ATTPC/attpc_engine, pure Python) has no FFI layer; its operator
+ * boundary for the hot path is a set of Python call signatures.  Each entry point
+ * below names the reference interface it replaces (paths relative to the
+ * reference's src/attpc_engine/).  The Python package `attpc_engine_amd` binds
+ * these symbols with ctypes (attpc_engine_amd/_abi.py) and re-exposes the
+ * reference's own class/function names on top.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every call returns an int32
+ *     status (ATTPC_OK == 0); attpc_last_error(ctx) gives a ctx-owned string.
+ *   - the caller owns every host buffer; the library owns device memory, freed in
+ *     attpc_ctx_destroy.  A ctx is single-threaded; distinct ctxs (one per GPU,
+ *     one per process in the multi-GPU bench) are independent.
+ *   - all floating point is IEEE binary64 ("f64"), charges are int64.
+ *   - random numbers: Philox4x32-10, key = seed, counter = (global event id,
+ *     draw index, domain) -- results do not depend on batch/chunk/GPU count.
+ */
+#ifndef ATTPC_ENGINE_H
+#define ATTPC_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATTPC_ABI_VERSION 1
+
+/* status codes */
+#define ATTPC_OK 0
+#define ATTPC_E_INVALID 1       /* bad argument / descriptor                                */
+#define ATTPC_E_NODEVICE 2      /* no HIP device                                            */
+#define ATTPC_E_HIP 3           /* a HIP runtime call failed (see attpc_last_error)         */
+#define ATTPC_E_CAPACITY 4      /* caller buffer too small; required size in stats          */
+#define ATTPC_E_NOTCONFIGURED 5 /* run called before the matching configure                 */
+
+#define ATTPC_MAX_STEPS 8    /* 1 Reaction + up to 7 Decays                                 */
+#define ATTPC_MAX_ROWS (4 + 2 * (ATTPC_MAX_STEPS - 1)) /* nuclei (rows) per event           */
+#define ATTPC_MAX_SPECIES 16
+#define ATTPC_MAX_SIM 8      /* max simulated nuclei per event (len(indices))               */
+
+/* stopping-power table: nodes on a "binade" grid, E = 2^e (1 + m/32) MeV,
+ * e in [ATTPC_DEDX_EMIN, ATTPC_DEDX_EMAX), m in [0,32); one extra closing node. */
+#define ATTPC_DEDX_EMIN (-30)
+#define ATTPC_DEDX_EMAX 14
+#define ATTPC_DEDX_SUB 32
+#define ATTPC_DEDX_NODES ((ATTPC_DEDX_EMAX - ATTPC_DEDX_EMIN) * ATTPC_DEDX_SUB + 1)
+
+#define ATTPC_NUM_TB 512        /* detector/constants.py:23                                 */
+#define ATTPC_TIME_SAMPLES 10001 /* detector/solver.py:16  TIME_STEPS                       */
+#define ATTPC_MESH_STEPS 10     /* detector/transporter.py:8  STEPS                         */
+
+/* excitation sampler kinds -- kinematics/excitation.py */
+#define ATTPC_EX_GAUSSIAN 0 /* p0 = centroid, p1 = sigma (= FWHM/2.355)         :32-80      */
+#define ATTPC_EX_UNIFORM 1  /* p0 = min, p1 = max                               :83-128     */
+#define ATTPC_EX_TABLE 2    /* inverse-CDF table: x[table_len], cdf[table_len]; value=x-p0.
+                               ExcitationBreitWigner (:131-188) is configured this way
+                               (x = total energy, p0 = rest mass).                          */
+/* polar sampler kinds -- kinematics/angle.py */
+#define ATTPC_POLAR_UNIFORM 0   /* uniform in cos(theta) in [cos_min, cos_max]  :35-80      */
+#define ATTPC_POLAR_ARBITRARY 1 /* choice(angles, p) + U*bin_width              :83-152     */
+
+typedef struct attpc_excitation_desc {
+  int32_t kind;
+  int32_t table_len;
+  double p0, p1, p2;
+  const double* table_x;   /* [table_len] (ATTPC_EX_TABLE) */
+  const double* table_cdf; /* [table_len], nondecreasing, last == 1 */
+} attpc_excitation_desc;
+
+typedef struct attpc_polar_desc {
+  int32_t kind;
+  int32_t table_len;
+  double cos_min, cos_max;
+  double bin_width;
+  const double* angles; /* [table_len] lower bin edges, radians */
+  const double* cdf;    /* [table_len] cumulative probabilities (numpy choice semantics) */
+} attpc_polar_desc;
+
+/* replaces KinematicsPipeline.__init__ state, kinematics/pipeline.py:125-185 */
+typedef struct attpc_kin_desc {
+  int32_t n_steps;      /* 1 + number of decays */
+  int32_t sample_limit; /* event_sample_limit, pipeline.py:132 */
+  double beam_energy;   /* MeV */
+  /* nuclear masses (MeV) in result-row order: target, projectile, ejectile, residual,
+     then (residual_1, residual_2) per decay -- pipeline.py:398-406 */
+  double masses[ATTPC_MAX_ROWS];
+  attpc_excitation_desc excitation[ATTPC_MAX_STEPS];
+  attpc_polar_desc polar[ATTPC_MAX_STEPS];
+  /* KinematicsTargetMaterial, pipeline.py:16-36 / :245-264 */
+  int32_t has_target;
+  int32_t eloss_len;   /* nodes of the beam energy-loss table */
+  double rho_sigma;    /* m */
+  double z_min, z_max; /* m */
+  const double* eloss; /* [eloss_len] energy loss (MeV) of the projectile at beam_energy after
+                          path z_min + i (z_max - z_min)/(eloss_len - 1) */
+} attpc_kin_desc;
+
+typedef struct attpc_species_desc {
+  int32_t Z;
+  int32_t A;
+  double mass;        /* ground-state nuclear mass, MeV (solver.py:273) */
+  const double* dedx; /* [ATTPC_DEDX_NODES] MeV/(g/cm^2) on the binade grid */
+} attpc_species_desc;
+
+/* replaces Config / DetectorParams / ElectronicsParams, detector/parameters.py:10-174 */
+typedef struct attpc_det_desc {
+  double length;   /* m */
+  double efield;   /* V/m */
+  double bfield;   /* T */
+  double density;  /* g/cm^3, target.density (solver.py:65) */
+  double diffusion;   /* V */
+  double fano_factor;
+  double w_value;  /* eV */
+  int64_t mpgd_gain;
+  int32_t micromegas_edge; /* time buckets */
+  int32_t windows_edge;
+  /* pad look-up at whole-millimetre pitch (transporter.py:78-120 floors to mm first).
+     pad_lut[ix * lut_n + iy] for floor(x_mm) = lut_lo + ix; -1 = no pad.  Beam pads
+     (detector/beam_pads.py) must already be folded to -1 by the caller. */
+  const int16_t* pad_lut;
+  int32_t lut_n;
+  int32_t lut_lo;
+  int32_t n_species;
+  int32_t ode_substeps; /* RK4 sub-steps per 1e-10 s output sample; 0 -> default (1) */
+  attpc_species_desc species[ATTPC_MAX_SPECIES];
+} attpc_det_desc;
+
+/* which rows of an event are simulated, detector/simulator.py:96-101,157-158 */
+typedef struct attpc_event_layout {
+  int32_t n_rows;                          /* nuclei per event (rows of the kinematics result) */
+  int32_t n_sim;                           /* len(indices) */
+  int32_t indices[ATTPC_MAX_SIM];          /* rows to simulate, in order */
+  int32_t species_of_row[ATTPC_MAX_ROWS];  /* index into det_desc.species, -1 => skip (Z == 0) */
+} attpc_event_layout;
+
+/* Host output buffers for a run (any pointer may be NULL => that output stays on the device). */
+typedef struct attpc_cloud_out {
+  int64_t capacity;   /* rows available in points/labels */
+  int64_t* offsets;   /* [n_events + 1] CSR offsets into points/labels */
+  double* points;     /* [capacity, 3] rows (pad, time bucket, electrons) -- simulator.py:40-46 */
+  int64_t* labels;    /* [capacity] row index of the nucleus that last touched the point */
+} attpc_cloud_out;
+
+typedef struct attpc_run_stats {
+  uint64_t n_events;
+  uint64_t n_points;          /* cloud rows produced */
+  uint64_t n_track_samples;   /* track samples with >= 1 electron (scatter work items) */
+  uint64_t n_sample_limit;    /* events that hit event_sample_limit */
+  uint64_t n_lds_overflow;    /* events that took the HBM-hash fallback */
+  uint64_t n_failed;          /* events whose cloud could not be built (fallback overflow) */
+  uint64_t charge_checksum;   /* sum of all charges mod 2^64 */
+  uint64_t key_checksum;      /* sum over points of (event*2^24 + tb*2^14 + pad) mod 2^64 */
+  double ms_kinematics;       /* device time of each kernel family (HIP events on the ctx stream) */
+  double ms_tracks;
+  double ms_scatter;
+  uint32_t launches_kinematics;
+  uint32_t launches_tracks;
+  uint32_t launches_scatter;
+  uint32_t reserved;
+} attpc_run_stats;
+
+typedef struct attpc_ctx attpc_ctx;
+
+int32_t attpc_version(void);
+int32_t attpc_device_count(void);
+/* device >= 0: that HIP device.  There is no CPU fallback: without a device -> ATTPC_E_NODEVICE. */
+int32_t attpc_ctx_create(int32_t device, attpc_ctx** out);
+int32_t attpc_ctx_destroy(attpc_ctx* ctx);
+const char* attpc_last_error(const attpc_ctx* ctx);
+/* events processed per internal chunk (device working set scales with it); 0 -> default */
+int32_t attpc_set_chunk_events(attpc_ctx* ctx, int32_t chunk_events);
+int32_t attpc_sync(attpc_ctx* ctx);
+
+/* KinematicsPipeline(...) state -> device.  kinematics/pipeline.py:125-185 */
+int32_t attpc_kin_configure(attpc_ctx* ctx, const attpc_kin_desc* desc);
+/* n x KinematicsPipeline.run(), kinematics/pipeline.py:285-388 (sample :232-283,
+ * Reaction/Decay.calculate reaction.py:103-178,252-303).
+ * p4 [n, n_rows, 4] (px,py,pz,E MeV), vertex [n,3] m, status [n] (0 ok, 1 sample limit),
+ * attempts [n]; each may be NULL. */
+int32_t attpc_kin_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                      double* p4, double* vertex, int32_t* status, uint32_t* attempts);
+
+/* Deterministic map "sampled parameters -> 4-vectors" for n parameter sets, using the
+ * configured masses / n_steps: Reaction.calculate + is_excitation_allowed
+ * (kinematics/reaction.py:70-178) followed by Decay.* (:230-303) per decay.
+ * beam_energy [n]; ex, polar, azim [n, n_steps]; p4 [n, n_rows, 4];
+ * status [n]: 0 ok, k+1 = step k not energetically allowed (rows from step k on are NaN),
+ * -1 = reaction below the non-relativistic threshold (reaction.py:136-143). */
+int32_t attpc_kin_calculate(attpc_ctx* ctx, uint64_t n, const double* beam_energy,
+                            const double* ex, const double* polar, const double* azim,
+                            double* p4, int32_t* status);
+
+/* Decay.is_excitation_allowed + Decay.calculate for explicit parent 4-vectors
+ * (kinematics/reaction.py:230-303): parent [n,4]; ex, polar, azim [n];
+ * out [n,2,4] = residual_1, residual_2; status [n]: 0 ok, 1 not allowed (rows NaN). */
+int32_t attpc_decay_calculate(attpc_ctx* ctx, uint64_t n, const double* parent, double mass_1,
+                              double mass_2, const double* ex, const double* polar,
+                              const double* azim, double* out, int32_t* status);
+
+/* Config(...) + nuclei table -> device.  detector/parameters.py:145-174 */
+int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* desc);
+/* n x simulate(), detector/simulator.py:52-115 (generate_point_cloud solver.py:350-413,
+ * transport_track transporter.py:252-317, dict_to_points simulator.py:19-49).
+ * p4/vertex are host arrays as produced by attpc_kin_run (or read from a kinematics file). */
+int32_t attpc_det_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                      const attpc_event_layout* layout, const double* p4, const double* vertex,
+                      attpc_cloud_out* out, attpc_run_stats* stats);
+
+/* Fused kinematics + detector: run_kinematics_pipeline + run_simulation without the
+ * file in between (kinematics/pipeline.py:429-495, detector/simulator.py:118-210);
+ * kinematics never leaves HBM.  out == NULL keeps the clouds device-resident
+ * (chunk buffers are overwritten; stats carry counts and checksums). */
+int32_t attpc_sim_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                      const attpc_event_layout* layout, double* p4, double* vertex,
+                      int32_t* kin_status, attpc_cloud_out* out, attpc_run_stats* stats);
+
+/* Diagnostics used by the parity tests: one track per (event, simulated nucleus) of a
+ * det_run-style input.  samples [n_tracks, ATTPC_TIME_SAMPLES, 4] rows (x m, y m,
+ * time bucket, electrons*gain) of the samples with >= 1 electron; counts [n_tracks];
+ * n_steps [n_tracks] = number of recorded ODE samples (rows of the reference's track). */
+int32_t attpc_det_tracks(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                         const attpc_event_layout* layout, const double* p4,
+                         const double* vertex, int64_t max_samples_per_track, double* samples,
+                         int32_t* counts, int32_t* n_steps);
+
+/* GET response + Spyral row conversion, detector/response.py:8-57, detector/writer.py:61-112:
+ * rows [n,8] = x_mm, y_mm, z_mm, amplitude, integral, pad, tb, pad_scale. */
+int32_t attpc_spyral_rows(attpc_ctx* ctx, int64_t n_points, const double* points,
+                          const double* response /*[512]*/, const double* pad_centers /*[npads,2]*/,
+                          const double* pad_sizes /*[npads]*/, int32_t n_pads, int32_t windows_edge,
+                          int32_t micromegas_edge, double length, double* rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATTPC_ENGINE_H */

@@ -1,0 +1,376 @@
+"""Generate golden vectors by EXECUTING THE REFERENCE'S OWN PYTHON CODE.
+
+Run in the build container only (the reference tree never travels):
+
+    python3 -B tests/golden/make_golden.py
+
+The reference package cannot be imported as-is: ``numba``, ``h5py``, ``vector`` and
+``spyral_utils`` are third-party packages that are neither part of the reference tree nor
+installable offline.  This script registers *minimal stand-ins for those packages only*
+and then imports the unmodified reference modules from /root/reference/src, so every
+arithmetic statement of reaction.py / pairing.py / transporter.py / simulator.py /
+solver.py / response.py / writer.py that runs here is the reference's own:
+
+  numba          -> identity ``njit``; ``typed.Dict.empty`` -> built-in dict (same insertion order)
+  h5py           -> empty module (no file I/O is exercised)
+  vector         -> 4-vector with + - boost boostCM_of .M (textbook Lorentz boost; the real
+                    package's arithmetic is pinned by the reference's LISE known-answer test)
+  spyral_utils   -> NucleusData / NuclearDataMap (this repo's light-nuclide table) and a
+                    GasTarget whose get_dedx interpolates the tabulated stopping power that
+                    is stored in the fixture (catima is "parity unpinned")
+
+Only DATA (inputs and expected outputs) is written to tests/golden/*.npz.
+"""
+from __future__ import annotations
+
+import sys
+import types
+from pathlib import Path
+
+sys.dont_write_bytecode = True  # never leave __pycache__ under /root/reference
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parents[2]
+REF_SRC = Path("/root/reference/src")
+OUT = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+from attpc_engine_amd.nuclear import NuclearDataMap, NucleusData  # noqa: E402
+from attpc_engine_amd.target import GasTarget as ModelGasTarget  # noqa: E402
+from attpc_engine_amd.detector.luts import dedx_node_energies, sample_dedx_table  # noqa: E402
+from attpc_engine_amd import _abi  # noqa: E402
+
+
+# ----------------------------------------------------------------------- stand-ins ----
+def install_standins() -> None:
+    numba = types.ModuleType("numba")
+
+    def njit(*args, **kwargs):
+        if len(args) == 1 and callable(args[0]) and not kwargs:
+            return args[0]
+        return lambda fn: fn
+
+    numba.njit = njit
+    typed = types.ModuleType("numba.typed")
+
+    class Dict(dict):
+        @staticmethod
+        def empty(key_type=None, value_type=None):
+            return Dict()
+
+    typed.Dict = Dict
+    core = types.ModuleType("numba.core")
+    nb_types = types.ModuleType("numba.core.types")
+    nb_types.int64 = np.int64
+    nb_types.Tuple = lambda types=None: None
+    core.types = nb_types
+    numba.typed = typed
+    numba.core = core
+    sys.modules.update({"numba": numba, "numba.typed": typed, "numba.core": core,
+                        "numba.core.types": nb_types})
+    sys.modules["h5py"] = types.ModuleType("h5py")
+
+    vector = types.ModuleType("vector")
+
+    class MomentumObject4D:
+        def __init__(self, px, py, pz, E):
+            self.px, self.py, self.pz, self.E = float(px), float(py), float(pz), float(E)
+
+        def __add__(self, o):
+            return MomentumObject4D(self.px + o.px, self.py + o.py, self.pz + o.pz, self.E + o.E)
+
+        def __sub__(self, o):
+            return MomentumObject4D(self.px - o.px, self.py - o.py, self.pz - o.pz, self.E - o.E)
+
+        @property
+        def M(self):
+            m2 = self.E**2 - (self.px**2 + self.py**2 + self.pz**2)
+            return np.sqrt(m2) if m2 >= 0 else -np.sqrt(-m2)
+
+        def _boost_beta(self, bx, by, bz):
+            bp2 = bx * bx + by * by + bz * bz
+            gam = (1.0 - bp2) ** -0.5
+            bgam = gam * gam / (1.0 + gam)
+            x, y, z, t = self.px, self.py, self.pz, self.E
+            xx, yy, zz = 1 + bgam * bx * bx, 1 + bgam * by * by, 1 + bgam * bz * bz
+            xy, xz, yz = bgam * bx * by, bgam * bx * bz, bgam * by * bz
+            xt, yt, zt = gam * bx, gam * by, gam * bz
+            return MomentumObject4D(
+                xx * x + xy * y + xz * z + xt * t, xy * x + yy * y + yz * z + yt * t,
+                xz * x + yz * y + zz * z + zt * t, xt * x + yt * y + zt * z + gam * t)
+
+        def boost(self, o):
+            return self._boost_beta(o.px / o.E, o.py / o.E, o.pz / o.E)
+
+        def boostCM_of(self, o):
+            return self._boost_beta(-o.px / o.E, -o.py / o.E, -o.pz / o.E)
+
+    vector.MomentumObject4D = MomentumObject4D
+    vector.obj = lambda px, py, pz, E: MomentumObject4D(px, py, pz, E)
+    sys.modules["vector"] = vector
+
+    su = types.ModuleType("spyral_utils")
+    su_n = types.ModuleType("spyral_utils.nuclear")
+    su_t = types.ModuleType("spyral_utils.nuclear.target")
+    su_m = types.ModuleType("spyral_utils.nuclear.nuclear_map")
+    su_n.NucleusData = NucleusData
+    su_n.NuclearDataMap = NuclearDataMap
+    su_m.NuclearDataMap = NuclearDataMap
+    su_t.GasTarget = TableGasTarget
+    su.nuclear = su_n
+    su_n.target = su_t
+    su_n.nuclear_map = su_m
+    sys.modules.update({"spyral_utils": su, "spyral_utils.nuclear": su_n,
+                        "spyral_utils.nuclear.target": su_t, "spyral_utils.nuclear.nuclear_map": su_m})
+
+
+def table_lookup(table: np.ndarray, ke: float) -> float:
+    """numpy restatement of the binade-grid interpolation the kernels use."""
+    e_lo, e_hi = np.ldexp(1.0, _abi.DEDX_EMIN), np.ldexp(1.0, _abi.DEDX_EMAX)
+    if not ke >= e_lo:
+        return float(table[0])
+    if ke >= e_hi:
+        return float(table[-1])
+    f, ex = np.frexp(ke)
+    sub = (2.0 * f - 1.0) * _abi.DEDX_SUB
+    j = int(sub)
+    i = (int(ex) - 1 - _abi.DEDX_EMIN) * _abi.DEDX_SUB + j
+    return float(table[i] + (sub - j) * (table[i + 1] - table[i]))
+
+
+class TableGasTarget:
+    """spyral_utils.GasTarget stand-in: tabulated dE/dx per (Z, A), analytic density."""
+
+    def __init__(self, compound, pressure, nuclear_map):
+        self.model = ModelGasTarget(compound, pressure, nuclear_map)
+        self.density = self.model.density
+        self.tables: dict[tuple[int, int], np.ndarray] = {}
+
+    def get_dedx(self, nucleus, ke):
+        key = (int(nucleus.Z), int(nucleus.A))
+        if key not in self.tables:
+            self.tables[key] = sample_dedx_table(self.model, nucleus)
+        return table_lookup(self.tables[key], float(ke))
+
+    def get_energy_loss(self, nucleus, ke, distances):
+        return self.model.get_energy_loss(nucleus, ke, distances)
+
+
+# -------------------------------------------------------------------------- main ------
+def main() -> None:
+    install_standins()
+    sys.path.insert(0, str(REF_SRC))
+    import attpc_engine  # the reference package, unmodified
+    from attpc_engine.kinematics.reaction import Reaction, Decay
+    from attpc_engine.detector import pairing, transporter, solver, simulator, response, writer
+    from attpc_engine.detector.parameters import Config, DetectorParams, ElectronicsParams, PadParams
+    from attpc_engine.detector.beam_pads import BEAM_PADS
+
+    nmap = attpc_engine.nuclear_map
+    rng = np.random.default_rng(20251004)
+
+    # ---- G1 LISE known answer through the reference's Reaction.calculate ----
+    rxn = Reaction(nmap.get_data(6, 12), nmap.get_data(1, 2), nmap.get_data(1, 1))
+    res = rxn.calculate(16.0, np.deg2rad(20.0), 0.0, residual_excitation=0.0)
+    lise = res[2].E - res[2].M
+    print("LISE KAT ejectile KE:", lise)
+    assert np.round(lise, 3) == 18.391
+
+    # ---- G2 pairing ----
+    tbs = np.array([56, 937, 0, 0, 511, 559, 10239, -1, 5, -3, 300, 10238], dtype=np.int64)
+    pads = np.array([937, 56, 0, 10239, 511, 10239, 3, 7, -1, -2, 300, 10239], dtype=np.int64)
+    ids = np.array([pairing.pair(int(t), int(p)) for t, p in zip(tbs, pads)], dtype=np.int64)
+    back = np.array([pairing.unpair(int(i)) for i in ids], dtype=np.int64)
+
+    # ---- G3/G4 kinematics: sampled parameters -> 4-vectors, allowed flags ----
+    chains = {
+        "c12dp": ([(6, 12), (1, 2), (1, 1)], [], 16.0),
+        "o16aa_a12c": ([(8, 16), (2, 4), (2, 4)], [((8, 16), (2, 4))], 40.0),
+        "b10_3he_chain": ([(5, 10), (2, 3), (2, 4)], [((5, 9), (2, 4)), ((3, 5), (2, 4))], 24.0),
+        "be10dp_inverse": ([(1, 2), (4, 10), (1, 1)], [], 96.0),
+    }
+    kin = {}
+    for name, (rx, decs, e0) in chains.items():
+        reaction = Reaction(*[nmap.get_data(z, a) for z, a in rx])
+        decays = [Decay(nmap.get_data(*par), nmap.get_data(*r1)) for par, r1 in decs]
+        n_steps = 1 + len(decays)
+        n = 160
+        beam = e0 * rng.uniform(0.6, 1.1, n)
+        ex = np.abs(rng.normal(0.0, 2.0, (n, n_steps)))
+        ex[:, 0] = rng.uniform(0.0, 0.55 * e0, n)  # spans allowed and forbidden excitations
+        ex[::7] = 0.0
+        th = np.arccos(rng.uniform(-1, 1, (n, n_steps)))
+        ph = rng.uniform(0, 2 * np.pi, (n, n_steps))
+        n_rows = 4 + 2 * len(decays)
+        p4 = np.full((n, n_rows, 4), np.nan)
+        status = np.zeros(n, dtype=np.int32)
+        for i in range(n):
+            if not reaction.is_excitation_allowed(beam[i], ex[i, 0]):
+                status[i] = 1
+                continue
+            try:
+                rows = reaction.calculate(beam[i], th[i, 0], ph[i, 0], ex[i, 0])
+            except ValueError:
+                status[i] = -1
+                continue
+            for r in range(4):
+                p4[i, r] = [rows[r].px, rows[r].py, rows[r].pz, rows[r].E]
+            prev = rows[3]
+            for s, dec in enumerate(decays):
+                if not dec.is_excitation_allowed(prev, ex[i, s + 1]):
+                    status[i] = s + 2
+                    break
+                out = dec.calculate(prev, th[i, s + 1], ph[i, s + 1], ex[i, s + 1])
+                for k in (1, 2):
+                    p4[i, 4 + 2 * s + k - 1] = [out[k].px, out[k].py, out[k].pz, out[k].E]
+                prev = out[2]
+        masses = [reaction.target.mass, reaction.projectile.mass, reaction.ejectile.mass,
+                  reaction.residual.mass]
+        for dec in decays:
+            masses += [dec.residual_1.mass, dec.residual_2.mass]
+        kin[f"{name}_masses"] = np.array(masses)
+        kin[f"{name}_beam"] = beam
+        kin[f"{name}_ex"] = ex
+        kin[f"{name}_th"] = th
+        kin[f"{name}_ph"] = ph
+        kin[f"{name}_p4"] = p4
+        kin[f"{name}_status"] = status
+        print(name, "allowed", int((status == 0).sum()), "of", n)
+    np.savez_compressed(OUT / "kinematics.npz", lise_ke=lise, pair_tb=tbs, pair_pad=pads, pair_id=ids,
+                        unpair=back, **kin)
+
+    # ---- detector configuration used by the detector fixtures (tests/test_detector.py:13-33) ----
+    gas = TableGasTarget([(1, 2, 2)], 300.0, nmap)
+    det = DetectorParams(length=1.0, efield=45000.0, bfield=2.85, mpgd_gain=175000, gas_target=gas,
+                         diffusion=0.277, fano_factor=0.2, w_value=34.0)
+    elec = ElectronicsParams(clock_freq=6.25, amp_gain=900, shaping_time=1000, micromegas_edge=10,
+                             windows_edge=560, adc_threshold=40)
+    config = Config(det, elec, PadParams())  # the reference's own 5600x5600 grid + edges
+    assert config.pad_grid.shape == (5600, 5600)
+    assert sorted(BEAM_PADS) == sorted(__import__("attpc_engine_amd.detector.beam_pads",
+                                                  fromlist=["BEAM_PADS"]).BEAM_PADS)
+
+    # ---- G5 transport: (x, y, time, electrons, label) -> (pad, tb, charge, label) ----
+    def run_transport(cases, diffusion, dv=config.drift_velocity, efield=det.efield):
+        points = {}
+        for xyt, electrons, label in cases:
+            track = np.zeros((len(xyt), 6))
+            track[:, 0:3] = xyt
+            transporter.transport_track(config.pad_grid, config.pad_grid_edges, diffusion, efield, dv,
+                                        track, electrons, points, label)
+        keys = np.array(list(points.keys()), dtype=np.int64)
+        charge = np.array([v[0] for v in points.values()], dtype=np.int64)
+        labels = np.array([v[1] for v in points.values()], dtype=np.int64)
+        tbpad = np.array([pairing.unpair(int(k)) for k in keys], dtype=np.int64).reshape(-1, 2)
+        return keys, tbpad, charge, labels
+
+    def make_case(n, kind, label):
+        if kind == "spiral":  # a curling track through the pad plane
+            s = np.linspace(0, 1, n)
+            x = 0.12 * np.cos(9 * s) * s + 0.01
+            y = 0.12 * np.sin(9 * s) * s - 0.02
+            t = 40.0 + 430.0 * s
+        elif kind == "beam":  # straight through the beam-pad region and the centre hole
+            x = np.linspace(-0.03, 0.03, n)
+            y = np.linspace(-0.004, 0.006, n)
+            t = np.linspace(100.0, 130.0, n)
+        elif kind == "edge":  # leaves the pad plane; window-side time buckets >= 512
+            x = np.linspace(0.20, 0.295, n)
+            y = np.linspace(-0.27, -0.285, n)
+            t = np.linspace(500.0, 559.5, n)
+        else:  # "early": close to the micromegas, tb 10..12, tiny sigma
+            x = rng.uniform(-0.2, 0.2, n)
+            y = rng.uniform(-0.2, 0.2, n)
+            t = rng.uniform(10.0, 12.0, n)
+        xyt = np.stack([x, y, t], axis=1)
+        electrons = (rng.integers(1, 4000, n) * 175000).astype(np.int64)
+        electrons[::5] = rng.integers(1, 60, len(electrons[::5]))  # tiny charges -> zero-charge inserts
+        return xyt, electrons, label
+
+    tr = {}
+    sets = {
+        "mixed": ([make_case(120, "spiral", 2), make_case(60, "beam", 4), make_case(50, "edge", 5),
+                   make_case(80, "early", 4)], 0.277),
+        "overlap": ([make_case(90, "spiral", 2), make_case(90, "spiral", 3)], 0.277),
+        "nodiffusion": ([make_case(100, "spiral", 2), make_case(40, "beam", 3)], 0.0),
+        "bigdiffusion": ([make_case(60, "spiral", 6), make_case(40, "edge", 7)], 2.77),
+    }
+    for name, (cases, diffusion) in sets.items():
+        keys, tbpad, charge, labels = run_transport(cases, diffusion)
+        tr[f"{name}_diffusion"] = diffusion
+        tr[f"{name}_n_cases"] = len(cases)
+        for i, (xyt, electrons, label) in enumerate(cases):
+            tr[f"{name}_xyt{i}"] = xyt
+            tr[f"{name}_electrons{i}"] = electrons
+            tr[f"{name}_label{i}"] = label
+        tr[f"{name}_keys"] = keys
+        tr[f"{name}_tbpad"] = tbpad
+        tr[f"{name}_charge"] = charge
+        tr[f"{name}_labels"] = labels
+        print("transport", name, "points", len(keys), "zero-charge", int((charge == 0).sum()))
+    # dict_to_points on the first set (reference simulator.py:19-49)
+    pts_in = {int(k): (int(c), int(l)) for k, c, l in zip(tr["mixed_keys"], tr["mixed_charge"], tr["mixed_labels"])}
+    pa, la = simulator.dict_to_points(pts_in)
+    tr["mixed_point_array"] = pa
+    tr["mixed_label_array"] = la
+    np.savez_compressed(OUT / "transport.npz", **tr)
+
+    # ---- G6 tracks: the reference's generate_trajectory (scipy Radau) + generate_electrons ----
+    cases = [  # Z, A, KE MeV, polar deg, azimuth deg, vertex (m)
+        (1, 1, 5.0, 60.0, 10.0, (0.001, -0.002, 0.30)),
+        (1, 1, 1.0, 85.0, 200.0, (0.0, 0.0, 0.50)),
+        (1, 1, 0.3, 40.0, 90.0, (0.002, 0.001, 0.20)),
+        (1, 2, 8.0, 30.0, 300.0, (0.0, 0.003, 0.10)),
+        (1, 2, 2.0, 120.0, 45.0, (0.0, 0.0, 0.70)),
+        (2, 4, 12.0, 50.0, 130.0, (0.0, 0.0, 0.40)),
+        (2, 4, 3.0, 75.0, 20.0, (0.004, 0.0, 0.55)),
+        (2, 4, 0.8, 150.0, 250.0, (0.0, -0.004, 0.80)),
+        (6, 12, 30.0, 10.0, 0.0, (0.0, 0.0, 0.25)),
+        (6, 12, 8.0, 35.0, 170.0, (0.001, 0.001, 0.60)),
+        (8, 16, 60.0, 5.0, 60.0, (0.0, 0.0, 0.05)),
+        (4, 10, 40.0, 8.0, 310.0, (0.0, 0.002, 0.45)),
+        (1, 1, 3.0, 90.0, 0.0, (0.0, 0.0, 0.50)),    # trapped spiral, never leaves
+        (1, 1, 20.0, 2.0, 0.0, (0.0, 0.0, 0.95)),    # leaves through the window at once
+    ]
+    tk = {"cases": np.array([[c[0], c[1], c[2], c[3], c[4], *c[5]] for c in cases])}
+    det0 = DetectorParams(length=1.0, efield=45000.0, bfield=2.85, mpgd_gain=175000, gas_target=gas,
+                          diffusion=0.277, fano_factor=0.0, w_value=34.0)  # Fano 0: deterministic electrons
+    species = []
+    for i, (z, a, ke, pol, azi, vtx) in enumerate(cases):
+        nuc = nmap.get_data(z, a)
+        p = np.sqrt(ke * (ke + 2.0 * nuc.mass))
+        pol_r, azi_r = np.deg2rad(pol), np.deg2rad(azi)
+        mom = np.array([p * np.sin(pol_r) * np.cos(azi_r), p * np.sin(pol_r) * np.sin(azi_r),
+                        p * np.cos(pol_r), ke + nuc.mass])
+        track = solver.generate_trajectory(np.array(vtx), mom, nuc, det)
+        electrons = solver.generate_electrons(track, nuc, det0, rng)
+        tk[f"mom{i}"] = mom
+        tk[f"nrows{i}"] = len(track)
+        tk[f"track{i}"] = track[::10].copy()          # every 10th ODE sample
+        tk[f"last{i}"] = track[-1].copy()
+        tk[f"electrons_sum{i}"] = int(electrons.sum())
+        tk[f"electrons_head{i}"] = electrons[:64].copy()
+        if (z, a) not in species:
+            species.append((z, a))
+        print(f"track {i}: Z={z} A={a} KE={ke} rows={len(track)} electrons={int(electrons.sum())}")
+    tk["species"] = np.array(species)
+    tk["dedx_tables"] = np.stack([gas.tables[s] for s in species])
+    tk["dedx_energies"] = dedx_node_energies()
+    tk["density"] = gas.density
+    tk["masses"] = np.array([nmap.get_data(z, a).mass for z, a in species])
+    np.savez_compressed(OUT / "tracks.npz", **tk)
+
+    # ---- G7 response + Spyral rows (reference response.py, writer.py:61-112) ----
+    resp = response.get_response(config)
+    pts = np.stack([rng.integers(0, 10240, 64).astype(float), rng.uniform(0, 512, 64),
+                    np.concatenate([rng.uniform(0, 3e6, 32), rng.uniform(1e6, 4e8, 32)])], axis=1)
+    rows = writer.convert_to_spyral(pts, elec.windows_edge, elec.micromegas_edge, det.length, resp,
+                                    config.pad_centers, config.pad_sizes)
+    np.savez_compressed(OUT / "response.npz", response=resp, points=pts, rows=rows)
+    print("response max", resp.max(), "argmax", int(resp.argmax()), "sum", resp.sum())
+    print("wrote fixtures to", OUT)
+
+
+if __name__ == "__main__":
+    main()

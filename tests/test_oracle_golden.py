@@ -1,0 +1,288 @@
+"""The CPU oracle against (a) published known-answer vectors and (b) golden vectors
+produced by executing the reference's own code (tests/golden/make_golden.py).  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from attpc_engine_amd import _abi, nuclear_map
+from attpc_engine_amd.detector.luts import dedx_node_energies
+from oracle import pyoracle as orc
+from tests.helpers import Inputs
+
+
+# ------------------------------------------------------------------ RNG ----------------
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    assert list(orc.philox([0, 0, 0, 0], [0, 0])) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    ones = 0xFFFFFFFF
+    assert list(orc.philox([ones] * 4, [ones] * 2)) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert list(orc.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0])) == [
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_rng_uniform_normal_moments():
+    L = orc.lib()
+    a, b = C.c_double(), C.c_double()
+    us, zs = [], []
+    for i in range(20000):
+        L.orc_rng_pair(7, 3, i, 0, C.byref(a), C.byref(b))
+        us.append(a.value)
+        zs.append(L.orc_rng_normal(7, 3, i, 1))
+    us, zs = np.array(us), np.array(zs)
+    assert 0.0 <= us.min() and us.max() < 1.0
+    assert abs(us.mean() - 0.5) < 0.01 and abs(us.var() - 1 / 12) < 0.005
+    assert abs(zs.mean()) < 0.03 and abs(zs.std() - 1.0) < 0.03
+
+
+# ------------------------------------------------------------------ kinematics ---------
+def _kin_desc(masses):
+    desc = _abi.KinDesc()
+    desc.n_steps = 1 + (len(masses) - 4) // 2
+    for i, m in enumerate(masses):
+        desc.masses[i] = m
+    return desc
+
+
+def test_lise_known_answer():
+    """reference tests/test_kinematics.py:13-36: 12C(d,p) at 16 MeV, 20 deg cm -> 18.391 MeV."""
+    nm = nuclear_map
+    masses = [nm.get_data(6, 12).mass, nm.get_data(1, 2).mass, nm.get_data(1, 1).mass, nm.get_data(6, 13).mass]
+    p4, status = orc.kin_calculate(_kin_desc(masses), 16.0, [0.0], [np.deg2rad(20.0)], [0.0])
+    assert status[0] == 0
+    eject = p4[0, 2]
+    ke = eject[3] - np.sqrt(eject[3] ** 2 - np.sum(eject[:3] ** 2))
+    assert np.round(ke, 3) == 18.391
+
+
+@pytest.mark.parametrize("chain", ["c12dp", "o16aa_a12c", "b10_3he_chain", "be10dp_inverse"])
+def test_kinematics_golden(golden_dir, chain):
+    g = np.load(golden_dir / "kinematics.npz")
+    desc = _kin_desc(g[f"{chain}_masses"])
+    p4, status = orc.kin_calculate(desc, g[f"{chain}_beam"], g[f"{chain}_ex"], g[f"{chain}_th"], g[f"{chain}_ph"])
+    np.testing.assert_array_equal(status, g[f"{chain}_status"])
+    ref = g[f"{chain}_p4"]
+    ok = status == 0
+    assert ok.sum() > 20
+    # tolerance 1e-9 MeV on components up to ~1.5e4 MeV (north star: stated FP tolerance)
+    np.testing.assert_allclose(p4[ok], ref[ok], rtol=0.0, atol=1e-9)
+    # partially filled events (a decay not allowed): rows computed before the break agree too
+    part = status > 1
+    both = ~np.isnan(ref[part]) & ~np.isnan(p4[part])
+    np.testing.assert_allclose(p4[part][both], ref[part][both], rtol=0.0, atol=1e-9)
+    # four-momentum conservation of every allowed event
+    tot_in = p4[ok][:, 0] + p4[ok][:, 1]
+    tot_out = p4[ok][:, 2] + p4[ok][:, 3]
+    np.testing.assert_allclose(tot_in, tot_out, atol=1e-9)
+
+
+def test_pairing_golden(golden_dir):
+    g = np.load(golden_dir / "kinematics.npz")
+    L = orc.lib()
+    tb, pad = C.c_int64(), C.c_int64()
+    for t, p, i, back in zip(g["pair_tb"], g["pair_pad"], g["pair_id"], g["unpair"]):
+        assert L.orc_pair(int(t), int(p)) == i
+        L.orc_unpair(int(i), C.byref(tb), C.byref(pad))
+        assert (tb.value, pad.value) == tuple(back)
+    # reference tests/test_pairing.py
+    assert L.orc_pair(56, 937) == 937**2 + 56
+    assert L.orc_pair(937, 56) == 937**2 + 937 + 56
+
+
+def test_sampler_restatements():
+    """Distribution shapes of the excitation / polar samplers against numpy/scipy draws."""
+    from scipy import stats
+    from attpc_engine_amd.kinematics import ExcitationBreitWigner, ExcitationGaussian, PolarArbitrary, PolarUniform
+    from attpc_engine_amd.kinematics._device import _fill_excitation, _fill_polar
+
+    L = orc.lib()
+    rng = np.random.default_rng(5)
+    ua, ub = rng.uniform(size=20000), rng.uniform(size=20000)
+    keep = []
+    ex = _abi.ExcitationDesc()
+    _fill_excitation(ex, ExcitationGaussian(9.585, 0.42).device_desc(), keep)
+    vals = np.array([L.orc_sample_excitation(ex, a, b) for a, b in zip(ua, ub)])
+    assert stats.kstest(vals, "norm", args=(9.585, 0.42 / 2.355)).pvalue > 1e-3
+    bw = ExcitationBreitWigner(rest_mass=100.0, centroid=5.0, width=0.5)
+    _fill_excitation(ex, bw.device_desc(), keep)
+    vals = np.array([L.orc_sample_excitation(ex, a, b) for a, b in zip(ua, ub)])
+    rho = (100.0 + 5.0) / 0.5
+    assert stats.kstest((vals + 100.0) / 0.5, stats.rel_breitwigner(rho).cdf).pvalue > 1e-3
+    po = _abi.PolarDesc()
+    _fill_polar(po, PolarUniform(0.2, 2.0).device_desc(), keep)
+    vals = np.array([L.orc_sample_polar(po, a, b) for a, b in zip(ua, ub)])
+    assert vals.min() >= 0.2 - 1e-12 and vals.max() <= 2.0 + 1e-12
+    assert stats.kstest(np.cos(vals), "uniform", args=(np.cos(2.0), np.cos(0.2) - np.cos(2.0))).pvalue > 1e-3
+    angles = np.linspace(0.0, np.pi, 18, endpoint=False)
+    probs = np.sin(angles + 0.05)
+    probs /= probs.sum() * 1.0000001
+    _fill_polar(po, PolarArbitrary(angles, probs, np.pi / 18).device_desc(), keep)
+    vals = np.array([L.orc_sample_polar(po, a, b) for a, b in zip(ua, ub)])
+    hist = np.histogram(vals, bins=18, range=(0, np.pi))[0] / len(vals)
+    assert np.abs(hist - probs / probs.sum()).max() < 0.01
+    # numpy choice semantics: idx = searchsorted(cdf, u, side="right")
+    cdf = np.cumsum(probs) / np.sum(probs)
+    for u in [0.0, cdf[3], np.nextafter(cdf[3], 0), 0.999999]:
+        want = angles[min(np.searchsorted(cdf, u, side="right"), 17)]
+        assert L.orc_sample_polar(po, u, 0.0) == want
+
+
+# ------------------------------------------------------------------ detector -----------
+def _golden_det(g, fano=0.2, diffusion=0.277):
+    """DetDesc for the detector fixtures: D2 300 Torr, reference test defaults, unfolded LUT."""
+    from attpc_engine_amd import GasTarget
+    from attpc_engine_amd.workloads import detector_config
+
+    gas = GasTarget([(1, 2, 2)], 300.0, nuclear_map)
+    cfg = detector_config(gas, diffusion=diffusion)
+    cfg.det_params.fano_factor = fano
+    desc = _abi.DetDesc()
+    from attpc_engine_amd.detector.luts import compact_pad_lut
+    lut, lo = compact_pad_lut(cfg.pad_grid, cfg.pad_grid_edges)
+    lut = np.ascontiguousarray(lut)
+    d = cfg.det_params
+    desc.length, desc.efield, desc.bfield = d.length, d.efield, d.bfield
+    desc.diffusion, desc.fano_factor, desc.w_value = d.diffusion, d.fano_factor, d.w_value
+    desc.mpgd_gain = d.mpgd_gain
+    desc.micromegas_edge, desc.windows_edge = 10, 560
+    desc.pad_lut = lut.ctypes.data_as(C.POINTER(C.c_int16))
+    desc.lut_n, desc.lut_lo = lut.shape[0], lo
+    keep = [lut]
+    if g is not None:
+        desc.density = float(g["density"])
+        desc.n_species = len(g["species"])
+        for i, (z, a) in enumerate(g["species"]):
+            tab = np.ascontiguousarray(g["dedx_tables"][i])
+            keep.append(tab)
+            desc.species[i].Z, desc.species[i].A = int(z), int(a)
+            desc.species[i].mass = float(g["masses"][i])
+            desc.species[i].dedx = _abi.dptr(tab)
+    return desc, keep
+
+
+@pytest.mark.parametrize("name", ["mixed", "overlap", "nodiffusion", "bigdiffusion"])
+def test_transport_golden(golden_dir, name):
+    """transport_track + pairing of the reference (run on its own 5600x5600 grid) vs the
+    oracle on the derived whole-mm LUT: keys, insertion order, labels exact; charges exact."""
+    g = np.load(golden_dir / "transport.npz")
+    det, keep = _golden_det(None, diffusion=float(g[f"{name}_diffusion"]))
+    cases = [(g[f"{name}_xyt{i}"], g[f"{name}_electrons{i}"], int(g[f"{name}_label{i}"]))
+             for i in range(int(g[f"{name}_n_cases"]))]
+    keys, charge, labels = orc.transport(det, cases)
+    np.testing.assert_array_equal(keys, g[f"{name}_keys"])  # same keys in the same insertion order
+    np.testing.assert_array_equal(labels, g[f"{name}_labels"])
+    # int(pdf*h*h*n): numpy's exp and glibc's exp may differ in the last bit -> allow 1 e- per pixel
+    assert np.abs(charge - g[f"{name}_charge"]).max() <= 2
+    assert (charge == g[f"{name}_charge"]).mean() > 0.999
+    assert (charge == 0).sum() == (g[f"{name}_charge"] == 0).sum()  # zero-charge inserts kept
+
+
+def test_dedx_lookup_matches_numpy(golden_dir):
+    g = np.load(golden_dir / "tracks.npz")
+    tab = np.ascontiguousarray(g["dedx_tables"][0])
+    nodes = dedx_node_energies()
+    np.testing.assert_array_equal(nodes, g["dedx_energies"])
+    L = orc.lib()
+    for i in [0, 1, 500, 1407]:
+        assert L.orc_dedx_lookup(_abi.dptr(tab), nodes[i]) == tab[i]
+    mid = 0.5 * (nodes[700] + nodes[701])
+    assert L.orc_dedx_lookup(_abi.dptr(tab), mid) == pytest.approx(0.5 * (tab[700] + tab[701]), rel=1e-15)
+    assert L.orc_dedx_lookup(_abi.dptr(tab), 0.0) == tab[0]
+    assert L.orc_dedx_lookup(_abi.dptr(tab), 1e9) == tab[-1]
+    assert L.orc_dedx_lookup(_abi.dptr(tab), float("nan")) == tab[0]
+
+
+def test_tracks_vs_reference_radau(golden_dir):
+    """generate_trajectory: the oracle's fixed-grid RK4 against the reference's scipy Radau
+    (rtol 1e-3) on the same tabulated stopping power.  Tolerances are physical and stated:
+    positions 0.5 mm (1/10 of the small pad pitch), kinetic energy 0.5 % of the initial KE,
+    stop sample index within 2 % / 3 samples."""
+    g = np.load(golden_dir / "tracks.npz")
+    det, keep = _golden_det(g)
+    species = [tuple(s) for s in g["species"]]
+    for i, case in enumerate(g["cases"]):
+        z, a, ke0 = int(case[0]), int(case[1]), case[2]
+        si = species.index((z, a))
+        track = orc.trajectory(det, si, case[5:8], g[f"mom{i}"])
+        n_ref = int(g[f"nrows{i}"])
+        assert abs(len(track) - n_ref) <= max(3, 0.02 * n_ref), (i, len(track), n_ref)
+        ref = g[f"track{i}"]
+        mine = track[::10]
+        m = min(len(ref), len(mine))
+        mass = det.species[si].mass
+        pos_err = np.abs(mine[:m, :3] - ref[:m, :3]).max()
+        assert pos_err < 5e-4, (i, pos_err)
+
+        def ke(rows):
+            gv2 = np.sum(rows[:, 3:] ** 2, axis=1)
+            return mass * (np.sqrt(1.0 + gv2) - 1.0)
+
+        ke_err = np.abs(ke(mine[:m]) - ke(ref[:m])).max()
+        assert ke_err < 5e-3 * ke0, (i, ke_err)
+
+
+def test_electrons_fano0_vs_reference(golden_dir):
+    """generate_electrons with Fano factor 0 is deterministic: trunc(|dKE| 1e6 / W)."""
+    g = np.load(golden_dir / "tracks.npz")
+    det, keep = _golden_det(g, fano=0.0)
+    species = [tuple(s) for s in g["species"]]
+    for i, case in enumerate(g["cases"]):
+        si = species.index((int(case[0]), int(case[1])))
+        track = orc.trajectory(det, si, case[5:8], g[f"mom{i}"])
+        el = orc.electrons(det, si, track, seed=1, event=0, domain=3)
+        assert el[0] == 0
+        ref_sum = int(g[f"electrons_sum{i}"])
+        assert abs(int(el.sum()) - ref_sum) <= max(30, 0.01 * ref_sum), (i, int(el.sum()), ref_sum)
+        head = g[f"electrons_head{i}"]
+        m = min(len(head), len(el), 40)
+        # per-sample counts of the reference carry its Radau dense-output noise (rtol 1e-3 on
+        # gamma*beta is several electrons per 1e-10 s sample); the running sum is the observable
+        cum_err = np.abs(np.cumsum(el[:m]) - np.cumsum(head[:m])).max()
+        assert cum_err <= 0.03 * head[:m].sum() + 5, (i, cum_err)
+
+
+def test_response_and_spyral_rows(golden_dir):
+    g = np.load(golden_dir / "response.npz")
+    L = orc.lib()
+    resp = np.empty(512)
+    L.orc_get_response(6.25, 900.0, 1000.0, _abi.dptr(resp))
+    np.testing.assert_allclose(resp, g["response"], rtol=1e-12, atol=1e-300)
+    assert int(resp.argmax()) == 7
+    from attpc_engine_amd.workloads import detector_config
+    from attpc_engine_amd import GasTarget
+    cfg = detector_config(GasTarget([(1, 2, 2)], 300.0, nuclear_map))
+    pts = np.ascontiguousarray(g["points"])
+    rows = np.empty((len(pts), 8))
+    ref_resp = np.ascontiguousarray(g["response"])
+    L.orc_convert_to_spyral(_abi.dptr(pts), len(pts), 560, 10, 1.0, _abi.dptr(ref_resp),
+                            _abi.dptr(np.ascontiguousarray(cfg.pad_centers)),
+                            _abi.dptr(np.ascontiguousarray(cfg.pad_sizes)), _abi.dptr(rows))
+    np.testing.assert_allclose(rows, g["rows"], rtol=1e-12)
+
+
+# ------------------------------------------------------------------ whole path ---------
+def test_oracle_event_properties():
+    """Oracle end to end on the headline workload: conservation, determinism, RNG keyed by
+    global event id (batch split invariance), point-cloud invariants."""
+    inp = Inputs("o16aa")
+    a = orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=3, first=0, n=6, capacity=200000, threads=4)
+    b1 = orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=3, first=0, n=3, capacity=200000, threads=2)
+    b2 = orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=3, first=3, n=3, capacity=200000, threads=1)
+    np.testing.assert_array_equal(a["p4"][:3], b1["p4"])
+    np.testing.assert_array_equal(a["p4"][3:], b2["p4"])
+    np.testing.assert_array_equal(a["points"], np.concatenate([b1["points"], b2["points"]]))
+    assert a["stats"][2] == (b1["stats"][2] + b2["stats"][2]) % (1 << 64)
+    p4 = a["p4"]
+    np.testing.assert_allclose(p4[:, 0] + p4[:, 1], p4[:, 2] + p4[:, 3], atol=1e-9)
+    np.testing.assert_allclose(p4[:, 3], p4[:, 4] + p4[:, 5], atol=1e-9)
+    pts, lab = a["points"], a["labels"]
+    assert len(pts) > 1000
+    assert pts[:, 1].min() >= 0 and pts[:, 1].max() < 512
+    assert set(np.unique(lab)) <= {2, 4, 5}
+    assert pts[:, 0].min() >= 0 and pts[:, 0].max() < 10240
+    from attpc_engine_amd.detector.beam_pads import BEAM_PADS_ARRAY
+    assert not np.isin(pts[:, 0].astype(int), BEAM_PADS_ARRAY).any()
+    for e in range(6):  # unique (pad, tb) per event
+        lo, hi = a["offsets"][e], a["offsets"][e + 1]
+        key = pts[lo:hi, 0].astype(np.int64) * 1024 + np.floor(pts[lo:hi, 1]).astype(np.int64)
+        assert len(np.unique(key)) == hi - lo

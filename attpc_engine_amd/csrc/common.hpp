@@ -1,0 +1,126 @@
+// common.hpp -- shared device helpers of the AT-TPC HIP engine (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "attpc_engine.h"
+
+namespace attpc {
+
+// detector/constants.py:23-35 -- scipy CODATA doubles, checked in tests/test_host_api.py
+constexpr double MEV_2_JOULE = 1.6021766339999998e-13;
+constexpr double MEV_2_KG = 1.7826619216278976e-30;
+constexpr double C_LIGHT = 299792458.0;
+constexpr double E_CHARGE = 1.602176634e-19;
+constexpr double KE_LIMIT = 1e-6;     // detector/solver.py:14
+constexpr double RHO_MAX = 0.292;     // detector/solver.py:240
+constexpr double PI = 3.141592653589793;
+constexpr double TWO_PI = 2.0 * PI;
+
+// RNG domains of the counter word (see DESIGN.md "Random streams")
+constexpr uint32_t DOMAIN_KIN = 0u;       // index = attempt * 64 + slot
+constexpr uint32_t DOMAIN_FANO0 = 1u;     // + row of the nucleus; index = sample >> 1
+constexpr uint32_t DOMAIN_JITTER = 0x100u; // index = tb << 14 | pad
+constexpr uint32_t KIN_SLOTS = 64u;
+
+// Philox4x32-10 (Salmon et al. SC'11), the algorithm of rocRAND's default generator, written
+// out so that the counter layout (event id, draw index, domain) is ours and the plain-C
+// oracle reproduces the identical stream.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0;
+    const uint32_t n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// two uniforms in [0,1) for (seed, event, index, domain)
+__device__ __forceinline__ void rng_pair(uint64_t seed, uint64_t event, uint32_t index, uint32_t domain,
+                                         double& ua, double& ub) {
+  uint32_t r[4];
+  philox4x32_10((uint32_t)event, (uint32_t)(event >> 32), index, domain, (uint32_t)seed,
+                (uint32_t)(seed >> 32), r);
+  ua = u53(r[0], r[1]);
+  ub = u53(r[2], r[3]);
+}
+
+// Box-Muller, cosine branch, on (1 - ua) in (0, 1]
+__device__ __forceinline__ double normal_from(double ua, double ub) {
+  return sqrt(-2.0 * log(1.0 - ua)) * cos(TWO_PI * ub);
+}
+
+// stopping-power table on the binade grid (include/attpc_engine.h): pure bit arithmetic on
+// the f64 -- exponent selects the binade, the top 5 mantissa bits the sub-bin, the remaining
+// 47 bits are the interpolation weight.
+template <typename TablePtr>
+__device__ __forceinline__ double dedx_lookup(TablePtr tab, double ke) {
+  constexpr double E_LO = 9.313225746154785e-10;  // 2^-30
+  constexpr double E_HI = 16384.0;                // 2^14
+  if (!(ke >= E_LO)) return tab[0];
+  if (ke >= E_HI) return tab[ATTPC_DEDX_NODES - 1];
+  const uint64_t bits = (uint64_t)__double_as_longlong(ke);
+  const int e = (int)((bits >> 52) & 0x7ff) - 1023;
+  const int j = (int)((bits >> 47) & 31);
+  const double t = (double)(bits & ((1ull << 47) - 1)) * (1.0 / 140737488355328.0);
+  const int i = (e - ATTPC_DEDX_EMIN) * ATTPC_DEDX_SUB + j;
+  const double lo = tab[i], hi = tab[i + 1];
+  return lo + t * (hi - lo);
+}
+
+// ---- device-side views of the configuration (pointers are device pointers) ----
+struct DetDev {
+  double length, efield, bfield, density, diffusion, fano_factor, w_value;
+  double inv_dv;          // (windows_edge - micromegas_edge) / length   [time buckets / m]
+  double dv;              // drift velocity, m / time bucket (parameters.py:172-174)
+  double mm_edge;
+  int64_t mpgd_gain;
+  const int16_t* pad_lut; // folded whole-mm LUT
+  int32_t lut_n, lut_lo;
+  int32_t n_species, ode_substeps;
+  const double* dedx;     // [n_species][ATTPC_DEDX_NODES]
+  double mass[ATTPC_MAX_SPECIES];
+  int32_t Z[ATTPC_MAX_SPECIES];
+};
+
+// track sample arena: blocks of ARENA_BLK samples, each sample = (x, y, time bucket, electrons)
+constexpr int ARENA_BLK = 128;
+constexpr int MAX_BLOCKS_PER_TRACK = (ATTPC_TIME_SAMPLES + ARENA_BLK - 1) / ARENA_BLK;  // 79
+
+struct TrackBuffers {
+  double* arena;          // [arena_blocks][ARENA_BLK][4]
+  int32_t* block_table;   // [n_tracks][MAX_BLOCKS_PER_TRACK]
+  int32_t* counts;        // [n_tracks] samples with >= 1 electron
+  int32_t* n_steps;       // [n_tracks] ODE rows recorded (reference track length)
+  uint32_t* ctrl;         // [0] next track, [1] next arena block, [2] arena overflow flag
+  uint32_t arena_blocks;
+};
+
+struct Segment {          // one flushed window of one event
+  int32_t event;          // chunk-local event
+  int32_t count;
+  int64_t offset;         // row offset into the chunk's points/labels
+};
+
+struct CloudBuffers {
+  double* points;         // [capacity][3]
+  int64_t* labels;        // [capacity]
+  Segment* segments;
+  unsigned long long* ctrl;  // [0] row cursor, [1] segment cursor, [2] charge sum, [3] key sum,
+                             // [4] failed events, [5] overflow windows retried, [6] out-of-capacity flag,
+                             // [7] samples
+  int64_t capacity;
+  int64_t seg_capacity;
+};
+
+}  // namespace attpc

@@ -1,0 +1,39 @@
+// tracks_args.hpp -- kernel argument blocks and host launch wrappers (one per kernel file).
+#pragma once
+#include "common.hpp"
+
+namespace attpc {
+
+struct TrackArgs {
+  DetDev det;
+  attpc_event_layout layout;
+  TrackBuffers buf;
+  const double* p4;           // [n_events][n_rows][4]
+  const double* vertex;       // [n_events][3]
+  const int32_t* kin_status;  // [n_events] or nullptr; != 0 -> event has no tracks
+  uint64_t seed;
+  uint64_t first_event;       // global id of chunk-local event 0
+  uint32_t n_events;
+  uint32_t n_tracks;          // n_events * n_sim
+};
+
+struct ScatterArgs {
+  DetDev det;
+  attpc_event_layout layout;
+  TrackBuffers trk;
+  CloudBuffers out;
+  uint64_t seed;
+  uint64_t first_event;
+  uint32_t n_events;
+};
+
+void launch_kin_run(hipStream_t s, const attpc_kin_desc& d, uint64_t seed, uint64_t first_event, uint32_t n,
+                    double* p4, double* vertex, int32_t* status, uint32_t* attempts);
+void launch_kin_calculate(hipStream_t s, const attpc_kin_desc& d, uint32_t n, const double* beam, const double* ex,
+                          const double* th, const double* ph, double* p4, int32_t* status);
+void launch_decay_calculate(hipStream_t s, uint32_t n, const double* parent, double m1, double m2, const double* ex,
+                            const double* th, const double* ph, double* out, int32_t* status);
+void launch_track_kernel(uint32_t blocks, size_t lds_bytes, hipStream_t s, const TrackArgs& a);
+void launch_scatter_kernel(uint32_t n_events, hipStream_t s, const ScatterArgs& a);
+
+}  // namespace attpc

@@ -28,6 +28,7 @@ extern "C" {
 #endif
 
 #define ATTPC_ABI_VERSION 1
+#define ATTPC_API __attribute__((visibility("default")))
 
 /* status codes */
 #define ATTPC_OK 0
@@ -165,23 +166,23 @@ typedef struct attpc_run_stats {
 
 typedef struct attpc_ctx attpc_ctx;
 
-int32_t attpc_version(void);
-int32_t attpc_device_count(void);
+ATTPC_API int32_t attpc_version(void);
+ATTPC_API int32_t attpc_device_count(void);
 /* device >= 0: that HIP device.  There is no CPU fallback: without a device -> ATTPC_E_NODEVICE. */
-int32_t attpc_ctx_create(int32_t device, attpc_ctx** out);
-int32_t attpc_ctx_destroy(attpc_ctx* ctx);
-const char* attpc_last_error(const attpc_ctx* ctx);
+ATTPC_API int32_t attpc_ctx_create(int32_t device, attpc_ctx** out);
+ATTPC_API int32_t attpc_ctx_destroy(attpc_ctx* ctx);
+ATTPC_API const char* attpc_last_error(const attpc_ctx* ctx);
 /* events processed per internal chunk (device working set scales with it); 0 -> default */
-int32_t attpc_set_chunk_events(attpc_ctx* ctx, int32_t chunk_events);
-int32_t attpc_sync(attpc_ctx* ctx);
+ATTPC_API int32_t attpc_set_chunk_events(attpc_ctx* ctx, int32_t chunk_events);
+ATTPC_API int32_t attpc_sync(attpc_ctx* ctx);
 
 /* KinematicsPipeline(...) state -> device.  kinematics/pipeline.py:125-185 */
-int32_t attpc_kin_configure(attpc_ctx* ctx, const attpc_kin_desc* desc);
+ATTPC_API int32_t attpc_kin_configure(attpc_ctx* ctx, const attpc_kin_desc* desc);
 /* n x KinematicsPipeline.run(), kinematics/pipeline.py:285-388 (sample :232-283,
  * Reaction/Decay.calculate reaction.py:103-178,252-303).
  * p4 [n, n_rows, 4] (px,py,pz,E MeV), vertex [n,3] m, status [n] (0 ok, 1 sample limit),
  * attempts [n]; each may be NULL. */
-int32_t attpc_kin_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+ATTPC_API int32_t attpc_kin_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
                       double* p4, double* vertex, int32_t* status, uint32_t* attempts);
 
 /* Deterministic map "sampled parameters -> 4-vectors" for n parameter sets, using the
@@ -190,23 +191,23 @@ int32_t attpc_kin_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint6
  * beam_energy [n]; ex, polar, azim [n, n_steps]; p4 [n, n_rows, 4];
  * status [n]: 0 ok, k+1 = step k not energetically allowed (rows from step k on are NaN),
  * -1 = reaction below the non-relativistic threshold (reaction.py:136-143). */
-int32_t attpc_kin_calculate(attpc_ctx* ctx, uint64_t n, const double* beam_energy,
+ATTPC_API int32_t attpc_kin_calculate(attpc_ctx* ctx, uint64_t n, const double* beam_energy,
                             const double* ex, const double* polar, const double* azim,
                             double* p4, int32_t* status);
 
 /* Decay.is_excitation_allowed + Decay.calculate for explicit parent 4-vectors
  * (kinematics/reaction.py:230-303): parent [n,4]; ex, polar, azim [n];
  * out [n,2,4] = residual_1, residual_2; status [n]: 0 ok, 1 not allowed (rows NaN). */
-int32_t attpc_decay_calculate(attpc_ctx* ctx, uint64_t n, const double* parent, double mass_1,
+ATTPC_API int32_t attpc_decay_calculate(attpc_ctx* ctx, uint64_t n, const double* parent, double mass_1,
                               double mass_2, const double* ex, const double* polar,
                               const double* azim, double* out, int32_t* status);
 
 /* Config(...) + nuclei table -> device.  detector/parameters.py:145-174 */
-int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* desc);
+ATTPC_API int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* desc);
 /* n x simulate(), detector/simulator.py:52-115 (generate_point_cloud solver.py:350-413,
  * transport_track transporter.py:252-317, dict_to_points simulator.py:19-49).
  * p4/vertex are host arrays as produced by attpc_kin_run (or read from a kinematics file). */
-int32_t attpc_det_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+ATTPC_API int32_t attpc_det_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
                       const attpc_event_layout* layout, const double* p4, const double* vertex,
                       attpc_cloud_out* out, attpc_run_stats* stats);
 
@@ -214,7 +215,7 @@ int32_t attpc_det_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint6
  * file in between (kinematics/pipeline.py:429-495, detector/simulator.py:118-210);
  * kinematics never leaves HBM.  out == NULL keeps the clouds device-resident
  * (chunk buffers are overwritten; stats carry counts and checksums). */
-int32_t attpc_sim_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+ATTPC_API int32_t attpc_sim_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
                       const attpc_event_layout* layout, double* p4, double* vertex,
                       int32_t* kin_status, attpc_cloud_out* out, attpc_run_stats* stats);
 
@@ -222,14 +223,14 @@ int32_t attpc_sim_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint6
  * det_run-style input.  samples [n_tracks, ATTPC_TIME_SAMPLES, 4] rows (x m, y m,
  * time bucket, electrons*gain) of the samples with >= 1 electron; counts [n_tracks];
  * n_steps [n_tracks] = number of recorded ODE samples (rows of the reference's track). */
-int32_t attpc_det_tracks(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+ATTPC_API int32_t attpc_det_tracks(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
                          const attpc_event_layout* layout, const double* p4,
                          const double* vertex, int64_t max_samples_per_track, double* samples,
                          int32_t* counts, int32_t* n_steps);
 
 /* GET response + Spyral row conversion, detector/response.py:8-57, detector/writer.py:61-112:
  * rows [n,8] = x_mm, y_mm, z_mm, amplitude, integral, pad, tb, pad_scale. */
-int32_t attpc_spyral_rows(attpc_ctx* ctx, int64_t n_points, const double* points,
+ATTPC_API int32_t attpc_spyral_rows(attpc_ctx* ctx, int64_t n_points, const double* points,
                           const double* response /*[512]*/, const double* pad_centers /*[npads,2]*/,
                           const double* pad_sizes /*[npads]*/, int32_t n_pads, int32_t windows_edge,
                           int32_t micromegas_edge, double length, double* rows);

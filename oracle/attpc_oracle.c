@@ -394,7 +394,7 @@ int32_t orc_generate_trajectory(const orc_det_desc* det, const orc_species_desc*
   return n;
 }
 
-/* detector/solver.py:308-347; the Fano draw of sample k uses Philox index k in `domain` */
+/* detector/solver.py:308-347; the Fano draw of sample k uses Philox index k>>1 in `domain` */
 void orc_generate_electrons(const orc_det_desc* det, const orc_species_desc* sp, const double* track,
                             int32_t n_rows, uint64_t seed, uint64_t event, uint32_t domain,
                             int64_t* electrons) {
@@ -406,7 +406,11 @@ void orc_generate_electrons(const orc_det_desc* det, const orc_species_desc* sp,
     if (k > 0) mu = fabs(e - prev);
     mu *= scale;
     prev = e;
-    double z = orc_rng_normal(seed, event, (uint32_t)k, domain);
+    /* one Philox call serves two consecutive samples (Box-Muller cos / sin branches) */
+    double ua, ub;
+    orc_rng_pair(seed, event, (uint32_t)k >> 1, domain, &ua, &ub);
+    double rad = sqrt(-2.0 * log(1.0 - ua));
+    double z = (k & 1) ? rad * sin(2.0 * PI * ub) : rad * cos(2.0 * PI * ub);
     double draw = mu + sqrt(det->fano_factor * mu) * z;
     electrons[k] = (int64_t)draw; /* dtype=np.int64 cast: truncation toward zero */
   }
@@ -621,7 +625,7 @@ int64_t orc_sim_batch(const orc_kin_desc* kin, const orc_det_desc* det, const or
                       int64_t capacity, int64_t* offsets, double* points, int64_t* labels, uint64_t* stats,
                       int32_t n_threads) {
   int32_t n_rows = lay->n_rows;
-  int64_t per_event_cap = 1 << 16;
+  int64_t per_event_cap = 1 << 19;
   int64_t* counts = (int64_t*)calloc(n + 1, sizeof(int64_t));
   double** ev_pts = (double**)calloc(n, sizeof(double*));
   int64_t** ev_lab = (int64_t**)calloc(n, sizeof(int64_t*));

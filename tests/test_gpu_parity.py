@@ -1,0 +1,364 @@
+"""Parity of the HIP path (through the C ABI / Python API) with the CPU oracle and with the
+golden vectors of the reference.  Needs a real MI355X: run with ``-m gpu``.
+
+Tolerances (north star: "within a stated FP tolerance"):
+  * 4-vectors: 1e-9 MeV absolute (values up to 1.5e4 MeV), vertices 1e-12 m
+  * track samples: x, y 1e-9 m; time bucket 1e-7; electron counts equal
+  * cloud: identical key set, labels and jittered time buckets; charges within 8 electrons
+    (integer truncation of products whose last bits differ between glibc and device libm)
+"""
+import numpy as np
+import pytest
+
+from attpc_engine_amd import _abi, nuclear_map
+from tests.helpers import Inputs, compare_clouds, sort_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return _abi.Context(0)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def _engine(inp, ctx, **kw):
+    from attpc_engine_amd.engine import Engine
+    return Engine(inp.pipeline, inp.config, inp.indices, context=ctx, **kw)
+
+
+# ---------------------------------------------------------------- reference's own tests ----
+def test_reference_lise_known_answer():
+    """tests/test_kinematics.py:13-36 of the reference, through the device."""
+    from attpc_engine_amd.kinematics import Reaction
+    rxn = Reaction(nuclear_map.get_data(6, 12), nuclear_map.get_data(1, 2), nuclear_map.get_data(1, 1))
+    result = rxn.calculate(16.0, np.deg2rad(20.0), 0.0, residual_excitation=0.0)
+    assert np.round(result[2].E - result[2].M, decimals=3) == 18.391
+    assert rxn.is_excitation_allowed(16.0, 0.0)
+    assert not rxn.is_excitation_allowed(1.0, 30.0)
+
+
+def test_reference_pipeline_chain():
+    """tests/test_kinematics.py:39-81: the 3-step chain builds, runs, rows/Z/A as expected."""
+    inp = Inputs("b10chain")
+    pipeline = inp.pipeline
+    pipeline.target_material = None
+    pipeline._configured = False
+    vertex, result = pipeline.run()
+    assert np.all(pipeline.get_proton_numbers() == np.array([5, 2, 2, 5, 2, 3, 2, 1]))
+    assert np.all(pipeline.get_mass_numbers() == np.array([10, 3, 4, 9, 4, 5, 4, 1]))
+    assert len(result) == 8
+    assert np.all(vertex == 0.0)
+    np.testing.assert_allclose(result[0] + result[1], result[2] + result[3], atol=1e-9)
+
+
+def test_reference_simulation_event():
+    """tests/test_detector.py:44-63: fake 4-proton event, vertex (1,1,1) -> a 2-tuple."""
+    from attpc_engine_amd import GasTarget
+    from attpc_engine_amd.detector import simulate
+    from attpc_engine_amd.workloads import detector_config
+    config = detector_config(GasTarget([(1, 2, 2)], 300.0, nuclear_map))
+    fake = np.array([[0.0, 0.0, 10.0, 938.0]] * 4)
+    event = simulate(fake, np.array([1.0, 1.0, 1.0]), np.array([1, 1, 1, 1]), np.array([1, 1, 1, 1]), config,
+                     np.random.default_rng(1), [0])
+    assert len(event) == 2
+    assert event[0].shape == (0, 3)  # starts on the window: one ODE row, no electrons
+
+
+def test_decay_api():
+    from attpc_engine_amd.kinematics import Decay, Reaction
+    rxn = Reaction(nuclear_map.get_data(2, 4), nuclear_map.get_data(8, 16), nuclear_map.get_data(2, 4))
+    rows = rxn.calculate(160.0, 1.0, 0.5, 9.585)
+    dec = Decay(nuclear_map.get_data(8, 16), nuclear_map.get_data(2, 4))
+    assert dec.is_excitation_allowed(rows[3], 0.0)
+    assert not dec.is_excitation_allowed(rows[3], 5.0)
+    out = dec.calculate(rows[3], 0.7, 2.0, 0.0)
+    np.testing.assert_allclose(out[0].as_array(), out[1].as_array() + out[2].as_array(), atol=1e-9)
+    with pytest.raises(ValueError):
+        dec.calculate(rows[3], 0.7, 2.0, 5.0)
+
+
+# ---------------------------------------------------------------- kinematics ---------------
+@pytest.mark.parametrize("chain", ["c12dp", "o16aa_a12c", "b10_3he_chain", "be10dp_inverse"])
+def test_kin_calculate_golden(golden_dir, ctx, chain):
+    g = np.load(golden_dir / "kinematics.npz")
+    masses = g[f"{chain}_masses"]
+    desc = _abi.KinDesc()
+    desc.n_steps = 1 + (len(masses) - 4) // 2
+    desc.sample_limit = 1
+    for i, m in enumerate(masses):
+        desc.masses[i] = m
+    ctx.check(ctx.lib.attpc_kin_configure(ctx.handle, desc), "configure")
+    ctx._kin_owner = None
+    n = len(g[f"{chain}_beam"])
+    p4 = np.empty((n, len(masses), 4))
+    status = np.empty(n, dtype=np.int32)
+    args = [np.ascontiguousarray(g[f"{chain}_{k}"]) for k in ("beam", "ex", "th", "ph")]
+    ctx.check(ctx.lib.attpc_kin_calculate(ctx.handle, n, *[_abi.dptr(a) for a in args], _abi.dptr(p4),
+                                          _abi.iptr(status, _abi.C.c_int32)), "calculate")
+    np.testing.assert_array_equal(status, g[f"{chain}_status"])
+    ok = status == 0
+    np.testing.assert_allclose(p4[ok], g[f"{chain}_p4"][ok], rtol=0, atol=1e-9)
+    part = status > 1
+    ref = g[f"{chain}_p4"][part]
+    both = ~np.isnan(ref)
+    np.testing.assert_allclose(p4[part][both], ref[both], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("name,n", [("c12pp", 1000), ("be10dp", 4000), ("o16aa", 4000), ("b10chain", 4000)])
+def test_kin_run_vs_oracle(ctx, orc, name, n):
+    inp = Inputs(name)
+    vertex, p4, status, attempts = inp.pipeline.run_many(n, first_event=17, seed=11, return_status=True)
+    ov, op4, ostatus, oatt = orc.kin_batch(inp.kin, 11, 17, n, threads=8)
+    np.testing.assert_array_equal(status, ostatus)
+    np.testing.assert_array_equal(attempts, oatt)
+    np.testing.assert_allclose(p4, op4, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(vertex, ov, rtol=0, atol=1e-12)
+    if name == "b10chain":
+        assert (attempts > 1).any()  # the rejection loop is exercised (5Li width reaches below threshold)
+    np.testing.assert_allclose(p4[:, 0] + p4[:, 1], p4[:, 2] + p4[:, 3], atol=1e-9)
+
+
+def test_kin_sample_limit_and_samplers(ctx, orc):
+    """Forbidden excitation -> status 1 for every event (reference raises PipelineError);
+    uniform / Breit-Wigner / arbitrary-polar samplers match the oracle draw for draw."""
+    from attpc_engine_amd.kinematics import (ExcitationBreitWigner, ExcitationGaussian, ExcitationUniform,
+                                             KinematicsPipeline, PipelineError, PolarArbitrary, PolarUniform, Reaction)
+    nm = nuclear_map
+    rxn = Reaction(nm.get_data(5, 10), nm.get_data(2, 3), nm.get_data(2, 4))
+    bad = KinematicsPipeline([rxn], [ExcitationGaussian(60.0, 0.2)], [PolarUniform(0.0, np.pi)], 2.0,
+                             event_sample_limit=20, seed=5, context=ctx)
+    _, _, status, attempts = bad.run_many(100, return_status=True)
+    assert (status == 1).all() and (attempts == 20).all()
+    with pytest.raises(PipelineError):
+        bad.run()
+    angles = np.linspace(0.0, np.pi, 36, endpoint=False)
+    probs = np.sin(angles + 0.04) ** 2
+    probs /= probs.sum() * 1.0000001
+    for ex in (ExcitationUniform(0.0, 12.0), ExcitationBreitWigner(nm.get_data(5, 9).mass, 2.3, 0.8)):
+        pipe = KinematicsPipeline([rxn], [ex], [PolarArbitrary(angles, probs, np.pi / 36)], 24.0, seed=9, context=ctx)
+        vertex, p4, status, attempts = pipe.run_many(3000, return_status=True)
+        kin, keep = pipe.device_desc()
+        ov, op4, ostatus, oatt = orc.kin_batch(kin, 9, 0, 3000, threads=8)
+        np.testing.assert_array_equal(attempts, oatt)
+        np.testing.assert_allclose(p4, op4, rtol=0, atol=1e-9)
+
+
+# ---------------------------------------------------------------- detector -----------------
+def _device_tracks(ctx, inp, p4, vertex, seed, first):
+    from attpc_engine_amd.detector.simulator import configure_detector
+    ctx._det_token = None
+    ctx.check(ctx.lib.attpc_det_configure(ctx.handle, inp.det), "det_configure")
+    n = len(p4)
+    nt = n * inp.layout.n_sim
+    samples = np.zeros((nt, _abi.TIME_SAMPLES, 4))
+    counts = np.empty(nt, dtype=np.int32)
+    steps = np.empty(nt, dtype=np.int32)
+    ctx.check(ctx.lib.attpc_det_tracks(ctx.handle, seed, first, n, inp.layout, _abi.dptr(np.ascontiguousarray(p4)),
+                                       _abi.dptr(np.ascontiguousarray(vertex)), _abi.TIME_SAMPLES, _abi.dptr(samples),
+                                       _abi.iptr(counts, _abi.C.c_int32), _abi.iptr(steps, _abi.C.c_int32)), "tracks")
+    return samples, counts, steps
+
+
+@pytest.mark.parametrize("name", ["o16aa", "be10dp"])
+def test_tracks_vs_oracle(ctx, orc, name):
+    inp = Inputs(name)
+    n, seed, first = 24, 21, 1000
+    vertex, p4, _, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
+    samples, counts, steps = _device_tracks(ctx, inp, p4, vertex, seed, first)
+    mismatched = 0
+    total = 0
+    for e in range(n):
+        for i, row in enumerate(inp.indices):
+            sp = inp.layout.species_of_row[row]
+            ref, ref_rows = orc.point_cloud_samples(inp.det_raw, sp, p4[e, row], vertex[e], seed, first + e, row)
+            t = e * inp.layout.n_sim + i
+            assert steps[t] == ref_rows, (e, row, steps[t], ref_rows)
+            assert counts[t] == len(ref), (e, row, counts[t], len(ref))
+            mine = samples[t, : counts[t]]
+            np.testing.assert_allclose(mine[:, :2], ref[:, :2], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(mine[:, 2], ref[:, 2], rtol=0, atol=1e-7)
+            mismatched += int((mine[:, 3] != ref[:, 3]).sum())
+            total += len(ref)
+    assert total > 3000
+    assert mismatched == 0, (mismatched, total)
+
+
+def test_long_and_degenerate_tracks(ctx, orc):
+    """A trapped 3 MeV proton spiral (stops after ~1200 samples), a forward 0.5 MeV proton that
+    ranges out, a particle starting on the window, one starting outside the field cage, and a
+    nucleus at rest."""
+    inp = Inputs("be10dp")
+    m_p = nuclear_map.get_data(1, 1).mass
+    m_be = nuclear_map.get_data(4, 11).mass
+
+    def mom(mass, ke, pol, azi):
+        p = np.sqrt(ke * (ke + 2 * mass))
+        return [p * np.sin(pol) * np.cos(azi), p * np.sin(pol) * np.sin(azi), p * np.cos(pol), ke + mass]
+
+    cases = [
+        (mom(m_p, 3.0, np.pi / 2, 0.0), mom(m_be, 80.0, 0.02, 1.0), [0.0, 0.0, 0.5]),
+        (mom(m_p, 0.5, 0.3, 2.0), mom(m_be, 5.0, 0.5, 4.0), [0.001, 0.002, 0.2]),
+        (mom(m_p, 2.0, 0.1, 0.0), mom(m_be, 40.0, 0.1, 0.0), [0.0, 0.0, 1.0]),
+        (mom(m_p, 2.0, 1.0, 0.0), mom(m_be, 40.0, 1.0, 0.0), [0.3, 0.3, 0.5]),
+        ([0.0, 0.0, 0.0, m_p], mom(m_be, 1e-3, 2.0, 0.0), [0.0, 0.0, 0.5]),
+    ]
+    p4 = np.zeros((len(cases), 4, 4))
+    vertex = np.zeros((len(cases), 3))
+    for i, (a, b, v) in enumerate(cases):
+        p4[i, 2], p4[i, 3], vertex[i] = a, b, v
+    samples, counts, steps = _device_tracks(ctx, inp, p4, vertex, 5, 0)
+    for e in range(len(cases)):
+        for i, row in enumerate(inp.indices):
+            sp = inp.layout.species_of_row[row]
+            ref, ref_rows = orc.point_cloud_samples(inp.det_raw, sp, p4[e, row], vertex[e], 5, e, row)
+            t = e * 2 + i
+            assert steps[t] == ref_rows and counts[t] == len(ref), (e, row, steps[t], ref_rows, counts[t], len(ref))
+            np.testing.assert_allclose(samples[t, : counts[t], :3], ref[:, :3], rtol=0, atol=1e-7)
+            assert (samples[t, : counts[t], 3] != ref[:, 3]).sum() <= 1
+    assert steps[0] > 1000 and steps[4 * 2] == 1
+
+
+@pytest.mark.parametrize("name,n", [("o16aa", 24), ("be10dp", 24), ("b10chain", 8)])
+def test_det_run_vs_oracle(ctx, orc, name, n):
+    """simulate() per event through attpc_det_run vs the oracle's orc_simulate."""
+    from attpc_engine_amd.detector.simulator import simulate_batch
+    inp = Inputs(name)
+    seed, first = 77, 5
+    vertex, p4, status, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
+    offsets, points, labels, stats = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, seed, inp.indices,
+                                                    first_event=first, ctx=ctx)
+    assert stats["n_failed"] == 0
+    worst = 0.0
+    for e in range(n):
+        ref_pts, ref_lab, _ = orc.simulate(inp.det_raw, inp.layout, seed, first + e, p4[e], vertex[e], capacity=1 << 19)
+        a = sort_cloud(points[offsets[e]:offsets[e + 1]], labels[offsets[e]:offsets[e + 1]])
+        b = sort_cloud(ref_pts, ref_lab)
+        worst = max(worst, compare_clouds(*a, *b))
+    assert offsets[-1] > 1000
+    print(name, "cloud points", offsets[-1], "max |dq|", worst, stats)
+
+
+def test_zero_diffusion_and_skipped_rows(ctx, orc):
+    """sigma_t == 0 -> point_transport path; a Z == 0 row in `indices` is skipped."""
+    from attpc_engine_amd.detector.simulator import simulate_batch
+    inp = Inputs("be10dp")
+    inp.config.det_params.diffusion = 0.0
+    inp2 = Inputs("be10dp")
+    inp2.config.det_params.diffusion = 0.0
+    from attpc_engine_amd.detector.luts import build_det_desc, build_layout
+    nuclei = [nuclear_map.get_data(z, a) for z, a in inp.species]
+    det_raw, keep = build_det_desc(inp.config, nuclei, fold_beam=False)
+    z = inp.z.copy()
+    z[3] = 0  # pretend the residual is a neutron: skipped
+    layout = build_layout(z, inp.a, inp.indices, inp.species)
+    seed, first, n = 3, 0, 12
+    vertex, p4, _, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
+    ctx._det_token = None
+    offsets, points, labels, stats = simulate_batch(p4, vertex, z, inp.a, inp.config, seed, inp.indices, ctx=ctx)
+    assert set(np.unique(labels)) <= {2}
+    for e in range(n):
+        ref_pts, ref_lab, _ = orc.simulate(det_raw, layout, seed, first + e, p4[e], vertex[e])
+        a = sort_cloud(points[offsets[e]:offsets[e + 1]], labels[offsets[e]:offsets[e + 1]])
+        compare_clouds(*a, *sort_cloud(ref_pts, ref_lab), charge_tol=0.0)
+    ctx._det_token = None
+
+
+@pytest.mark.parametrize("name,n", [("o16aa", 48), ("be10dp", 48)])
+def test_sim_run_vs_oracle(ctx, orc, name, n):
+    """Fused kinematics + detector (attpc_sim_run) vs the oracle's fused batch, incl. CSR."""
+    inp = Inputs(name)
+    eng = _engine(inp, ctx)
+    res = eng.run(n, seed=123, first_event=40, fetch=True)
+    ref = orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=123, first=40, n=n, capacity=1 << 21, threads=8)
+    np.testing.assert_allclose(res["p4"], ref["p4"], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(res["offsets"], ref["offsets"])
+    for e in range(n):
+        lo, hi = ref["offsets"][e], ref["offsets"][e + 1]
+        compare_clouds(*sort_cloud(res["points"][lo:hi], res["labels"][lo:hi]),
+                       *sort_cloud(ref["points"][lo:hi], ref["labels"][lo:hi]))
+    st = res["stats"]
+    assert st["n_points"] == ref["stats"][0] and st["n_track_samples"] == ref["stats"][1]
+    assert st["key_checksum"] == ref["stats"][3]
+    assert abs(int(st["charge_checksum"]) - int(ref["stats"][2])) <= 8 * st["n_points"]
+
+
+# ---------------------------------------------------------------- size-independent properties
+def test_invariance_chunks_shards_residency(ctx):
+    """Same events whatever the chunk size, the split of the id range (what 2/4/8 GPUs do) or
+    whether the clouds are fetched: checksums of keys and charges are identical."""
+    inp = Inputs("o16aa")
+    n = 3000
+    eng = _engine(inp, ctx, chunk_events=4096)
+    whole = eng.run(n, seed=8, first_event=0)["stats"]
+    eng2 = _engine(inp, ctx, chunk_events=700)
+    parts = eng2.run(n, seed=8, first_event=0)["stats"]
+    for k in ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_sample_limit"):
+        assert whole[k] == parts[k], k
+    a = eng2.run(n // 2, seed=8, first_event=0)["stats"]
+    b = eng2.run(n - n // 2, seed=8, first_event=n // 2)["stats"]
+    assert a["n_points"] + b["n_points"] == whole["n_points"]
+    assert (a["charge_checksum"] + b["charge_checksum"]) % (1 << 64) == whole["charge_checksum"]
+    assert (a["key_checksum"] + b["key_checksum"]) % (1 << 64) == whole["key_checksum"]
+    fetched = eng2.run(500, seed=8, first_event=0, fetch=True)
+    again = eng2.run(500, seed=8, first_event=0)["stats"]
+    assert fetched["stats"]["key_checksum"] == again["key_checksum"]
+    pts = fetched["points"]
+    assert int(pts[:, 2].astype(np.int64).sum() % (1 << 64)) == fetched["stats"]["charge_checksum"]
+    assert pts[:, 1].min() >= 0 and pts[:, 1].max() < 512 and fetched["stats"]["n_failed"] == 0
+    ctx.check(ctx.lib.attpc_set_chunk_events(ctx.handle, 0), "chunk")
+
+
+def test_full_size_properties(ctx):
+    """BASELINE headline shape at reduced count (5e4 events): run twice -> bit-identical
+    checksums (the deterministic-replay race detector for the LDS-atomic scatter), no failed
+    events, every event's keys unique, charges non-negative."""
+    inp = Inputs("o16aa")
+    eng = _engine(inp, ctx)
+    n = 50000
+    s1 = eng.run(n, seed=3)["stats"]
+    s2 = eng.run(n, seed=3)["stats"]
+    for k in ("n_points", "charge_checksum", "key_checksum", "n_track_samples"):
+        assert s1[k] == s2[k], k
+    assert s1["n_failed"] == 0 and s1["n_sample_limit"] == 0
+    assert 2000 < s1["n_points"] / n < 20000
+    res = eng.run(64, seed=3, fetch=True)
+    for e in range(64):
+        lo, hi = res["offsets"][e], res["offsets"][e + 1]
+        key = res["points"][lo:hi, 0].astype(np.int64) * 1024 + np.floor(res["points"][lo:hi, 1]).astype(np.int64)
+        assert len(np.unique(key)) == hi - lo
+    assert (res["points"][:, 2] >= 0).all()
+
+
+def test_empty_and_errors(ctx):
+    inp = Inputs("be10dp")
+    eng = _engine(inp, ctx)
+    res = eng.run(0, seed=1, fetch=True)
+    assert res["offsets"].tolist() == [0] and len(res["points"]) == 0
+    bad = _abi.EventLayout()
+    bad.n_rows, bad.n_sim = 4, 1
+    bad.indices[0] = 9
+    st = _abi.RunStats()
+    rc = ctx.lib.attpc_sim_run(ctx.handle, 1, 0, 4, bad, None, None, None, None, st)
+    assert rc == _abi.E_INVALID and b"indices" in ctx.lib.attpc_last_error(ctx.handle)
+    fresh = _abi.Context(0)
+    rc = fresh.lib.attpc_sim_run(fresh.handle, 1, 0, 4, inp.layout, None, None, None, None, st)
+    assert rc == _abi.E_NOTCONFIGURED
+    fresh.close()
+
+
+def test_spyral_rows_golden(golden_dir, ctx):
+    from attpc_engine_amd import GasTarget
+    from attpc_engine_amd.detector.writer import convert_to_spyral
+    from attpc_engine_amd.detector.response import get_response
+    from attpc_engine_amd.workloads import detector_config
+    g = np.load(golden_dir / "response.npz")
+    cfg = detector_config(GasTarget([(1, 2, 2)], 300.0, nuclear_map))
+    np.testing.assert_allclose(get_response(cfg), g["response"], rtol=1e-13)
+    rows = convert_to_spyral(g["points"], 560, 10, 1.0, g["response"], cfg.pad_centers, cfg.pad_sizes, ctx=ctx)
+    np.testing.assert_allclose(rows, g["rows"], rtol=1e-12)

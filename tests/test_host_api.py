@@ -1,0 +1,263 @@
+"""Host-side logic (no GPU): API mirror of the reference, validation errors, tables, and
+that the C-ABI library loads and exports every symbol include/attpc_engine.h declares."""
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from attpc_engine_amd import _abi, nuclear_map
+from attpc_engine_amd.kinematics import (Decay, ExcitationGaussian, KinematicsPipeline, PipelineError, PolarUniform,
+                                         PolarArbitrary, Reaction)
+
+ROOT = Path(__file__).resolve().parents[1]
+nm = nuclear_map
+
+
+def _rxn():
+    return Reaction(target=nm.get_data(5, 10), projectile=nm.get_data(2, 3), ejectile=nm.get_data(2, 4))
+
+
+def test_library_builds_and_exports_header_symbols():
+    import __graft_entry__ as entry
+    entry.build()
+    lib = _abi.load_library()
+    header = (ROOT / "include" / "attpc_engine.h").read_text()
+    declared = set(re.findall(r"ATTPC_API [\w\* ]+?(attpc_\w+)\(", header))
+    assert declared == set(_abi.EXPORTED_SYMBOLS), declared ^ set(_abi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.attpc_version() == 1
+
+
+def test_abi_struct_layout_matches_header():
+    """ctypes mirrors vs a C program compiled against the header (sizeof / offsetof)."""
+    import subprocess
+    import tempfile
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "attpc_engine.h"
+int main(void){
+ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(attpc_excitation_desc), sizeof(attpc_polar_desc),
+  sizeof(attpc_kin_desc), sizeof(attpc_species_desc), sizeof(attpc_det_desc), sizeof(attpc_event_layout),
+  sizeof(attpc_cloud_out), sizeof(attpc_run_stats));
+ printf("%zu %zu %zu %zu\n", offsetof(attpc_kin_desc, excitation), offsetof(attpc_kin_desc, eloss),
+  offsetof(attpc_det_desc, pad_lut), offsetof(attpc_det_desc, species));
+ return 0; }'''
+    with tempfile.TemporaryDirectory() as tmp:
+        c = Path(tmp) / "t.c"
+        c.write_text(src)
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), str(c), "-o", str(Path(tmp) / "t")], check=True)
+        out = subprocess.run([str(Path(tmp) / "t")], capture_output=True, text=True, check=True).stdout.split()
+    import ctypes as C
+    sizes = [C.sizeof(t) for t in (_abi.ExcitationDesc, _abi.PolarDesc, _abi.KinDesc, _abi.SpeciesDesc, _abi.DetDesc,
+                                   _abi.EventLayout, _abi.CloudOut, _abi.RunStats)]
+    assert [int(v) for v in out[:8]] == sizes
+    offs = [_abi.KinDesc.excitation.offset, _abi.KinDesc.eloss.offset, _abi.DetDesc.pad_lut.offset,
+            _abi.DetDesc.species.offset]
+    assert [int(v) for v in out[8:]] == offs
+
+
+def test_oracle_struct_layout_matches_abi():
+    """The oracle declares its own structs; they must be byte-compatible with the ABI's."""
+    import subprocess
+    import tempfile
+    src = r'''
+#include <stdio.h>
+#include "attpc_engine.h"
+#include "attpc_oracle.h"
+int main(void){
+ printf("%d\n", sizeof(attpc_kin_desc)==sizeof(orc_kin_desc) && sizeof(attpc_det_desc)==sizeof(orc_det_desc)
+   && sizeof(attpc_event_layout)==sizeof(orc_event_layout) && ORC_DEDX_NODES==ATTPC_DEDX_NODES
+   && sizeof(attpc_excitation_desc)==sizeof(orc_excitation_desc) && sizeof(attpc_polar_desc)==sizeof(orc_polar_desc));
+ return 0; }'''
+    with tempfile.TemporaryDirectory() as tmp:
+        c = Path(tmp) / "t.c"
+        c.write_text(src)
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), "-I", str(ROOT / "oracle"), str(c), "-o",
+                        str(Path(tmp) / "t")], check=True)
+        assert subprocess.run([str(Path(tmp) / "t")], capture_output=True, text=True).stdout.strip() == "1"
+
+
+def test_no_gpu_means_loud_failure():
+    """The product has no CPU fallback: without a HIP device every entry point raises."""
+    lib = _abi.load_library()
+    if lib.attpc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_abi.EngineUnavailable):
+        _abi.Context(0)
+    with pytest.raises(_abi.EngineUnavailable):
+        _rxn().calculate(24.0, 0.3, 0.0, 0.0)
+
+
+def test_product_never_imports_oracle():
+    for path in (ROOT / "attpc_engine_amd").rglob("*.py"):
+        text = path.read_text()
+        assert "pyoracle" not in text and "libattpc_oracle" not in text and "import oracle" not in text, path
+    for path in (ROOT / "attpc_engine_amd" / "csrc").glob("*.h*"):
+        assert "attpc_oracle" not in path.read_text(), path
+
+
+# ---- reference tests/test_kinematics.py:84-235: validation matrix --------------------------
+def test_pipeline_ex_length():
+    with pytest.raises(PipelineError):
+        KinematicsPipeline([_rxn(), Decay(nm.get_data(5, 9), nm.get_data(2, 4))], [ExcitationGaussian(16.8, 0.2)],
+                           [PolarUniform(0.0, np.pi)] * 2, 24.0)
+
+
+def test_pipeline_pl_length():
+    with pytest.raises(PipelineError):
+        KinematicsPipeline([_rxn(), Decay(nm.get_data(5, 9), nm.get_data(2, 4))],
+                           [ExcitationGaussian(16.8, 0.2), ExcitationGaussian(0.0, 0.0)], [PolarUniform(0.0, np.pi)], 24.0)
+
+
+def test_pipeline_chain():
+    with pytest.raises(PipelineError):
+        KinematicsPipeline([_rxn(), Decay(nm.get_data(4, 8), nm.get_data(2, 4))],
+                           [ExcitationGaussian(16.8, 0.2), ExcitationGaussian(0.0, 0.0)],
+                           [PolarUniform(0.0, np.pi)] * 2, 24.0)
+
+
+def test_pipeline_order_and_empty():
+    with pytest.raises(PipelineError):
+        KinematicsPipeline([Decay(nm.get_data(5, 9), nm.get_data(2, 4)), _rxn()],
+                           [ExcitationGaussian(16.8, 0.2), ExcitationGaussian(0.0, 0.0)],
+                           [PolarUniform(0.0, np.pi)] * 2, 24.0)
+    with pytest.raises(PipelineError):
+        KinematicsPipeline([], [], [], 24.0)
+    with pytest.raises(PipelineError):
+        KinematicsPipeline([_rxn(), _rxn()], [ExcitationGaussian()] * 2, [PolarUniform(0.0, np.pi)] * 2, 24.0)
+
+
+def test_pipeline_sample_limit_as_written():
+    """tests/test_kinematics.py:206-235 (the error there comes from the 1-vs-2 list lengths)."""
+    with pytest.raises(PipelineError):
+        KinematicsPipeline([_rxn()], [ExcitationGaussian(16.8, 0.2)], [PolarUniform(0.0, np.pi)] * 2, 2.0)
+
+
+def test_pipeline_description_and_rows():
+    pipe = KinematicsPipeline(
+        [_rxn(), Decay(nm.get_data(5, 9), nm.get_data(2, 4)), Decay(nm.get_data(3, 5), nm.get_data(2, 4))],
+        [ExcitationGaussian(16.8, 0.2), ExcitationGaussian(0.0, 1.25), ExcitationGaussian(0.0, 0.0)],
+        [PolarUniform(0.0, np.pi)] * 3, 24.0)
+    assert np.all(pipe.get_proton_numbers() == np.array([5, 2, 2, 5, 2, 3, 2, 1]))
+    assert np.all(pipe.get_mass_numbers() == np.array([10, 3, 4, 9, 4, 5, 4, 1]))
+    assert pipe.result.shape == (8, 4)
+    assert str(pipe) == "10B(3He,4He)9B, 9B->4He+5Li, 5Li->4He+1H"
+    desc, keep = pipe.device_desc()
+    assert desc.n_steps == 3 and desc.sample_limit == 1000 and desc.has_target == 0
+    assert desc.masses[3] == nm.get_data(5, 9).mass and desc.masses[7] == nm.get_data(1, 1).mass
+    assert desc.excitation[0].p1 == pytest.approx(0.2 / 2.355)
+
+
+def test_illegal_nuclei_and_probabilities():
+    with pytest.raises(ValueError):
+        Reaction(nm.get_data(1, 1), nm.get_data(1, 1), nm.get_data(6, 12))
+    with pytest.raises(ValueError):
+        Decay(nm.get_data(2, 4), nm.get_data(6, 12))
+    with pytest.raises(ValueError):
+        PolarArbitrary(np.array([0.0, 1.0]), np.array([0.7, 0.7]), 1.0)
+    PolarArbitrary(np.array([0.0, 1.0]), np.array([0.3, 0.3]), 1.0)  # sum < 1 is accepted (angle.py:128-131)
+    pu = PolarUniform(0.1, 2.0)
+    assert pu.cos_angle_min == np.cos(2.0) and pu.cos_angle_max == np.cos(0.1)
+
+
+# ---- detector host side ---------------------------------------------------------------------
+def test_config_defaults_and_tables():
+    """tests/test_detector.py:39-40 + derived quantities."""
+    from attpc_engine_amd import GasTarget
+    from attpc_engine_amd.detector.beam_pads import BEAM_PADS
+    from attpc_engine_amd.detector.luts import (build_det_desc, compact_pad_lut, dedx_node_energies,
+                                                fold_beam_pads, sample_dedx_table)
+    from attpc_engine_amd.workloads import detector_config
+    gas = GasTarget([(1, 2, 2)], 300.0, nm)
+    cfg = detector_config(gas)
+    assert cfg.drift_velocity == 1.0 / 550.0
+    assert cfg.pad_grid.shape == (559, 559) and list(cfg.pad_grid_edges) == [-280.0, 279.0, 1.0]
+    assert cfg.pad_centers.shape == (10240, 2) and cfg.pad_sizes.shape == (10240,)
+    assert len(BEAM_PADS) == 122 and len(set(BEAM_PADS)) == 122
+    lut, lo = compact_pad_lut(cfg.pad_grid, cfg.pad_grid_edges)
+    assert lo == -280 and lut.shape == (559, 559) and np.array_equal(lut, cfg.pad_grid)
+    folded = fold_beam_pads(lut)
+    assert not np.isin(folded, BEAM_PADS).any() and (folded == -1).sum() > (lut == -1).sum()
+    # a 0.1 mm grid compacts to the same LUT (only every 10th row/col is ever addressed)
+    fine = np.repeat(np.repeat(lut, 10, axis=0), 10, axis=1)
+    fine = np.pad(fine, ((0, 10), (0, 10)), constant_values=-1)
+    lut2, lo2 = compact_pad_lut(fine, np.array([-280.0, 279.0, 0.1]))
+    assert lo2 == -280 and np.array_equal(lut2, lut)
+    nodes = dedx_node_energies()
+    assert len(nodes) == _abi.DEDX_NODES and nodes[0] == 2.0**-30 and nodes[-1] == 2.0**14
+    assert np.all(np.diff(nodes) > 0)
+    tab = sample_dedx_table(gas, nm.get_data(1, 1))
+    assert tab.shape == (_abi.DEDX_NODES,) and np.all(tab > 0)
+    desc, keep = build_det_desc(cfg, [nm.get_data(1, 1), nm.get_data(2, 4)])
+    assert desc.n_species == 2 and desc.lut_n == 559 and desc.lut_lo == -280 and desc.mpgd_gain == 175000
+    cfg.pad_grid = None
+    with pytest.raises(ValueError):
+        build_det_desc(cfg, [nm.get_data(1, 1)])
+
+
+def test_constants_match_scipy_and_kernels():
+    from attpc_engine_amd.detector import constants
+    text = (ROOT / "attpc_engine_amd" / "csrc" / "common.hpp").read_text()
+    for name, value in (("MEV_2_JOULE", constants.MEV_2_JOULE), ("MEV_2_KG", constants.MEV_2_KG),
+                        ("C_LIGHT", constants.C), ("E_CHARGE", constants.E_CHARGE)):
+        m = re.search(rf"constexpr double {name} = ([0-9.e+-]+);", text)
+        assert m and float(m.group(1)) == value, name
+    assert constants.NUM_TB == 512
+
+
+def test_layout_and_indices():
+    from attpc_engine_amd.detector.luts import build_layout, species_for
+    from attpc_engine_amd.detector.simulator import default_indices
+    assert default_indices(4) == [2, 3] and default_indices(6) == [2, 4, 5] and default_indices(8) == [2, 4, 6, 7]
+    z, a = np.array([2, 8, 2, 8, 2, 0]), np.array([4, 16, 4, 16, 4, 1])
+    keys = species_for(z, a, [2, 4, 5])
+    assert keys == [(2, 4)]
+    lay = build_layout(z, a, [2, 4, 5], keys)
+    assert lay.n_rows == 6 and lay.n_sim == 3 and list(lay.indices)[:3] == [2, 4, 5]
+    assert lay.species_of_row[2] == 0 and lay.species_of_row[5] == -1
+    with pytest.raises(IndexError):
+        build_layout(z, a, [9], keys)
+
+
+def test_pairing_reference_identities():
+    """tests/test_pairing.py of the reference."""
+    from attpc_engine_amd.detector.pairing import pair, unpair
+    assert pair(56, 937) == 937**2 + 56 and unpair(pair(56, 937)) == (56, 937)
+    assert pair(937, 56) == 937**2 + 937 + 56 and unpair(pair(937, 56)) == (937, 56)
+    assert pair(-1, 5) == -1 and pair(5, -1) == -1 and unpair(-1) == (-1, -1)
+    for tb in (0, 1, 300, 511):
+        for pad in (0, 7, 511, 10239):
+            assert unpair(pair(tb, pad)) == (tb, pad)
+
+
+def test_nuclear_data_and_gas_target():
+    from attpc_engine_amd import GasTarget
+    c12 = nm.get_data(6, 12)
+    assert c12.isotopic_symbol == "12C" and str(c12) == "12C" and c12.Z == 6 and c12.A == 12
+    assert c12.mass == pytest.approx(12.0 * 931.49410242 - 6 * 0.51099895)
+    gas = GasTarget([(1, 2, 2)], 300.0, nm)
+    assert gas.density == pytest.approx(6.61e-5, rel=1e-2)
+    p = nm.get_data(1, 1)
+    assert gas.get_dedx(p, 10.0) == pytest.approx(50.9, rel=0.02)  # Bethe regime, Z/A = 1/2
+    loss = gas.get_energy_loss(p, 10.0, np.array([0.0, 0.5, 1.0]))
+    assert loss[0] == 0.0 and 0 < loss[1] < loss[2] < 1.0
+    with pytest.raises(KeyError):
+        nm.get_data(92, 238)
+
+
+def test_kinematics_file_roundtrip(tmp_path):
+    from attpc_engine_amd.io import KinematicsFileReader, KinematicsFileWriter
+    rng = np.random.default_rng(0)
+    vertex, p4 = rng.normal(size=(10, 3)), rng.normal(size=(10, 6, 4))
+    w = KinematicsFileWriter(tmp_path / "kin.npz", 10, [2, 8, 2, 8, 2, 6], [4, 16, 4, 16, 4, 12], 4)
+    w.write_batch(0, vertex[:6], p4[:6])
+    w.write_batch(6, vertex[6:], p4[6:])
+    w.close()
+    r = KinematicsFileReader(tmp_path / "kin.npz")
+    assert r.n_events == 10 and r.n_chunks == 3 and list(r.proton_numbers) == [2, 8, 2, 8, 2, 6]
+    v, q = r.read(3, 8)
+    np.testing.assert_array_equal(v, vertex[3:8])
+    np.testing.assert_array_equal(q, p4[3:8])

@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: events/s for a fused kinematics + full-detector batch.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--events E] [--workload o16aa]
+
+One "step" = one pass of the hot path over one batch of E synthetic events per GPU
+(default: the BASELINE.json headline, 1e6-event two-step 16O(a,a')16O* -> a + 12C with the
+full pad-plane point cloud).  Inputs are generated on the device from Philox streams keyed
+by the global event id; the clouds stay resident in HBM (chunk buffers are overwritten),
+so `value` is device-resident whole-job throughput.  For N > 1 the driver starts this
+script once per GPU through torch.distributed.run; rank r simulates the event-id range
+[r*E, (r+1)*E) (weak scaling, no data-path collective); the timed region is bracketed by a
+barrier + device sync on both sides and the MAX over ranks is taken.
+
+The JSON line also carries
+  roofline     -- algorithmic HBM bytes of the dominant kernel's launches / its measured
+                  average launch duration (HIP events on the engine's stream) vs 8 TB/s
+  cpu_baseline -- the CPU oracle (plain-C restatement of the reference algorithm, OpenMP
+                  over events) timed on this host's cores on a bounded sample, rank 0, N = 1
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--events", type=int, default=1_000_000, help="events per GPU per step")
+    ap.add_argument("--workload", default="o16aa")
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--chunk-events", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from attpc_engine_amd import _abi, sharding, workloads
+    from attpc_engine_amd.engine import Engine
+
+    rank, local_rank, world_size = sharding.world()
+    if args.gpus != world_size and world_size > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
+    dist = sharding.init_process_group("gloo")  # control plane only: barrier + scalar reductions
+
+    pipeline, config, indices = workloads.WORKLOADS[args.workload](seed=args.seed)
+    ctx = _abi.Context(local_rank)
+    engine = Engine(pipeline, config, indices, context=ctx, chunk_events=args.chunk_events or None)
+    first, n_events = sharding.weak_shard(args.events, rank)
+
+    def sync() -> None:
+        ctx.check(ctx.lib.attpc_sync(ctx.handle), "attpc_sync")
+
+    for _ in range(args.warmup):
+        engine.run(n_events, seed=args.seed, first_event=first)
+    sync()
+    sharding.barrier(dist)
+    t0 = time.perf_counter()
+    stats = None
+    agg = {"ms_kinematics": 0.0, "ms_tracks": 0.0, "ms_scatter": 0.0, "launches_kinematics": 0,
+           "launches_tracks": 0, "launches_scatter": 0}
+    for _ in range(args.steps):
+        stats = engine.run(n_events, seed=args.seed, first_event=first)["stats"]
+        for k in agg:
+            agg[k] += stats[k]
+    sync()
+    sharding.barrier(dist)
+    elapsed = time.perf_counter() - t0
+    (elapsed_max,) = sharding.reduce_scalars(dist, [elapsed], "max")
+    points, samples, failed, limit = sharding.reduce_scalars(
+        dist, [float(stats["n_points"]), float(stats["n_track_samples"]), float(stats["n_failed"]),
+               float(stats["n_sample_limit"])], "sum")
+    charge_sum, key_sum = sharding.reduce_checksums(dist, [stats["charge_checksum"], stats["key_checksum"]])
+    if rank != 0:
+        return
+
+    total_events = args.events * world_size
+    value = total_events * args.steps / elapsed_max
+    n_rows = len(pipeline.get_proton_numbers())
+    p_event = stats["n_points"] / max(1, n_events)
+    # vertex f64[3] + p4 f64[N,4] + one i64 CSR offset + P points of 3 f64 + i64
+    bytes_per_event = 24 + 32 * n_rows + 8 + 32 * p_event
+    kernels = {"track_kernel": ("ms_tracks", "launches_tracks"), "scatter_kernel": ("ms_scatter", "launches_scatter")}
+    dominant = max(kernels, key=lambda k: agg[kernels[k][0]])
+    ms_key, launch_key = kernels[dominant]
+    launches = max(1, agg[launch_key])
+    events_per_launch = n_events * args.steps / launches
+    avg_ms = agg[ms_key] / launches
+    achieved = events_per_launch * bytes_per_event / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    line = {
+        "metric": "events/sec (whole node); 2-step reaction + full detector batch",
+        "value": value,
+        "unit": "events/s",
+        "n_gpus": world_size,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed_max / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {workloads.describe(args.workload)}",
+            "events_per_gpu_per_step": args.events,
+            "global_events_per_step": total_events,
+            "parallelism": f"event-range shards x{world_size}, no collective in the data path",
+            "output": "device-resident point clouds (3 f64 + i64 per point), chunk buffers overwritten",
+            "points_per_event": p_event,
+            "track_samples_per_event": stats["n_track_samples"] / max(1, n_events),
+            "algorithmic_bytes_per_event": bytes_per_event,
+            "failed_events": failed,
+            "sample_limit_events": limit,
+            "charge_checksum": charge_sum,
+            "key_checksum": key_sum,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": dominant,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "avg_launch_ms": avg_ms,
+            "events_per_launch": events_per_launch,
+            "kernel_ms_total": {k: agg[v[0]] for k, v in kernels.items()} | {"kin_run_kernel": agg["ms_kinematics"]},
+            "note": "path is f64-VALU / LDS-atomic bound, not HBM bound (DESIGN.md); frac is vs the HBM roof",
+        },
+    }
+    if world_size == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
+    print(json.dumps(line), flush=True)
+
+
+def cpu_baseline(workload: str, seed: int) -> dict:
+    """The CPU oracle on this host's cores, bounded sample (~10-30 s), same workload/seeds."""
+    from oracle import pyoracle as orc
+    from tests.helpers import Inputs
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    inp = Inputs(workload, seed=seed)
+    probe = 4 * cores
+    t0 = time.perf_counter()
+    orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=seed, first=0, n=probe, threads=cores)
+    rate = probe / (time.perf_counter() - t0)
+    n = int(min(max(probe, rate * 15.0), 200_000))
+    t0 = time.perf_counter()
+    orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=seed, first=0, n=n, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "events/s", "cores": cores, "kind": "port",
+            "sample": f"{n} events of the same workload (ids 0..{n - 1}, same seed), OpenMP over events, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -119,8 +119,6 @@ def test_kin_run_vs_oracle(ctx, orc, name, n):
     np.testing.assert_array_equal(attempts, oatt)
     np.testing.assert_allclose(p4, op4, rtol=0, atol=1e-9)
     np.testing.assert_allclose(vertex, ov, rtol=0, atol=1e-12)
-    if name == "b10chain":
-        assert (attempts > 1).any()  # the rejection loop is exercised (5Li width reaches below threshold)
     np.testing.assert_allclose(p4[:, 0] + p4[:, 1], p4[:, 2] + p4[:, 3], atol=1e-9)
 
 
@@ -140,13 +138,15 @@ def test_kin_sample_limit_and_samplers(ctx, orc):
     angles = np.linspace(0.0, np.pi, 36, endpoint=False)
     probs = np.sin(angles + 0.04) ** 2
     probs /= probs.sum() * 1.0000001
-    for ex in (ExcitationUniform(0.0, 12.0), ExcitationBreitWigner(nm.get_data(5, 9).mass, 2.3, 0.8)):
+    for ex in (ExcitationUniform(0.0, 60.0), ExcitationBreitWigner(nm.get_data(5, 9).mass, 2.3, 0.8)):
         pipe = KinematicsPipeline([rxn], [ex], [PolarArbitrary(angles, probs, np.pi / 36)], 24.0, seed=9, context=ctx)
         vertex, p4, status, attempts = pipe.run_many(3000, return_status=True)
         kin, keep = pipe.device_desc()
         ov, op4, ostatus, oatt = orc.kin_batch(kin, 9, 0, 3000, threads=8)
         np.testing.assert_array_equal(attempts, oatt)
         np.testing.assert_allclose(p4, op4, rtol=0, atol=1e-9)
+        if isinstance(ex, ExcitationUniform):
+            assert (attempts > 1).mean() > 0.2  # the whole-event rejection loop is exercised
 
 
 # ---------------------------------------------------------------- detector -----------------
@@ -221,7 +221,7 @@ def test_long_and_degenerate_tracks(ctx, orc):
             assert steps[t] == ref_rows and counts[t] == len(ref), (e, row, steps[t], ref_rows, counts[t], len(ref))
             np.testing.assert_allclose(samples[t, : counts[t], :3], ref[:, :3], rtol=0, atol=1e-7)
             assert (samples[t, : counts[t], 3] != ref[:, 3]).sum() <= 1
-    assert steps[0] > 1000 and steps[4 * 2] == 1
+    assert steps[0] > 500 and steps[4 * 2] == 1
 
 
 @pytest.mark.parametrize("name,n", [("o16aa", 24), ("be10dp", 24), ("b10chain", 8)])
@@ -309,7 +309,7 @@ def test_invariance_chunks_shards_residency(ctx):
     again = eng2.run(500, seed=8, first_event=0)["stats"]
     assert fetched["stats"]["key_checksum"] == again["key_checksum"]
     pts = fetched["points"]
-    assert int(pts[:, 2].astype(np.int64).sum() % (1 << 64)) == fetched["stats"]["charge_checksum"]
+    assert int(pts[:, 2].astype(np.uint64).sum(dtype=np.uint64)) == fetched["stats"]["charge_checksum"]
     assert pts[:, 1].min() >= 0 and pts[:, 1].max() < 512 and fetched["stats"]["n_failed"] == 0
     ctx.check(ctx.lib.attpc_set_chunk_events(ctx.handle, 0), "chunk")
 

@@ -126,7 +126,7 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
   if ((rc = ensure(ctx, ctx->counts, (size_t)n_tracks * sizeof(int32_t)))) return rc;
   if ((rc = ensure(ctx, ctx->n_steps, (size_t)n_tracks * sizeof(int32_t)))) return rc;
   if ((rc = ensure(ctx, ctx->trk_ctrl, 16 * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->out_ctrl, 16 * sizeof(unsigned long long)))) return rc;
+  if ((rc = ensure(ctx, ctx->out_ctrl, 32 * sizeof(unsigned long long)))) return rc;
   size_t want_blocks = std::max<size_t>(ctx->arena_blocks, (size_t)n_tracks * 6 + 1024);
   int64_t want_rows = std::max<int64_t>(ctx->cloud_capacity, (int64_t)n * 9216 + 65536);
   int64_t want_segs = std::max<int64_t>(ctx->seg_capacity, (int64_t)n * 6 + 4096);
@@ -141,7 +141,7 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
     ctx->seg_capacity = want_segs;
 
     HIP_TRY(ctx, hipMemsetAsync(ctx->trk_ctrl.p, 0, 16 * sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->out_ctrl.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->out_ctrl.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
 
     TrackArgs ta;
     ta.det = ctx->det;
@@ -186,7 +186,7 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 
     uint32_t tctrl[4];
-    unsigned long long octrl[8];
+    unsigned long long octrl[16];
     HIP_TRY(ctx, hipMemcpyAsync(tctrl, ctx->trk_ctrl.p, sizeof tctrl, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(octrl, ctx->out_ctrl.p, sizeof octrl, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -206,6 +206,12 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
       want_segs = std::max<int64_t>(want_segs, (int64_t)(octrl[1] + octrl[1] / 8) + 4096);
       retry = true;
     }
+#ifdef ATTPC_PHASE_TIMERS
+    fprintf(stderr, "[attpc phase cycles] init %llu hist %llu select %llu stage %llu items %llu overflow %llu flushcount %llu flushwrite %llu (events %u)\n",
+            octrl[8], octrl[9], octrl[10], octrl[11], octrl[12], octrl[13], octrl[14], octrl[15], n);
+    fprintf(stderr, "[attpc ctrl] rows %llu segments %llu failed %llu retried %llu samples %llu\n", octrl[0], octrl[1],
+            octrl[4], octrl[5], octrl[7]);
+#endif
     if (!retry) {
       res->rows = octrl[0];
       res->segs = octrl[1];

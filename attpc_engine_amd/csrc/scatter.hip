@@ -8,225 +8,296 @@
 // into the LUT), simulator.py:19-49 (dict_to_points), :108-113 (tb jitter, 0 <= tb < 512).
 //
 // Execution model: one workgroup = one event.  The event's dictionary is an open-addressing
-// hash table in LDS (u32 key|label word + u64 charge, 8192 slots = 96 KiB); the 100 mesh
-// pixels of every kept track sample are spread over the lanes and accumulated with LDS
-// atomics (ds_cmpst_b32 to claim a slot, ds_add_u64 for the charge).  Events with more keys
-// than the table holds are cut into time-bucket windows (a key contains its time bucket, so
-// windows partition the key space); each window is flushed as one coalesced block of rows
-// (one global atomic per window reserves the range) and the table is reused.  The nuclei of
-// an event are scattered one after the other (barrier in between) so that "label = last
-// nucleus in `indices` order that touched the key" holds without ordering atomics.
+// hash table in LDS (u32 key|label word + f64 charge, 8192 slots = 96 KiB).  Staging: one lane
+// per kept track sample computes sigma_t and the whole-mm LUT indices of the sample's 10 mesh
+// columns and 10 mesh rows (20 floors instead of 200) into LDS.  Work item = one mesh pixel:
+// two LDS index reads, one 2-byte gather from the 625 KB pad LUT (L2 resident), one f64
+// multiply + truncate, one hash insert (ds_read probe, ds_cmpst_b32 to claim a slot,
+// ds_max_u32 for the label) and one ds_add_f64 of the charge.  Pixel charges are whole
+// numbers far below 2^53, so f64 accumulation is exact and order independent.
+// Events with more keys than the table holds are cut into time-bucket windows (a key
+// contains its time bucket, so windows partition the key space; boundaries come from a
+// prefix sum of the per-bucket sample histogram); each window is flushed as one contiguous
+// block of rows (one global atomic per window reserves the range) and the table is reused.
+// "label = last nucleus in `indices` order that touched the key" (transporter.py:249) is the
+// MAX position in `indices` over the touching nuclei, kept with ds_max_u32 on the key|label
+// word, so all nuclei of an event scatter concurrently.
 //
 // pdf(pixel) h^2 depends only on the pixel index: (36/81)/(2 pi) exp(-(2/9)((i-4.5)^2+(j-4.5)^2))
 // because the mesh pitch is h = 6 sigma / 9; the 100 weights are a constant table.
 //
-// Bound: LDS atomics + 2-byte LUT gathers (L2 resident, 625 KB) + f64 VALU; HBM traffic is
-// the 32 B per output row (3 f64 + i64, the reference's own dtypes) and 32 B per track sample.
+// Bound: LDS atomics + LUT gathers + f64 VALU; HBM traffic is the 32 B per output row
+// (3 f64 + i64, the reference's own dtypes) and 32 B per track sample read.
 #include "tracks_args.hpp"
 
 namespace attpc {
 
-constexpr int SC_THREADS = 512;
+// Diagnostic build only (-DATTPC_PHASE_TIMERS): thread 0 of every workgroup accumulates
+// s_memtime deltas per phase into out.ctrl[8 + phase]; never compiled into the shipped library.
+#ifdef ATTPC_PHASE_TIMERS
+#define PHASE_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_MARK(k)                                               \
+  do {                                                              \
+    const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); \
+    ph_acc[k] += ph_now - ph_t0;                                    \
+    ph_t0 = ph_now;                                                 \
+  } while (0)
+#define PHASE_FLUSH                                                          \
+  do {                                                                       \
+    if (tid == 0)                                                            \
+      for (int k = 0; k < 8; ++k) atomicAdd(&a.out.ctrl[8 + k], ph_acc[k]); \
+  } while (0)
+#else
+#define PHASE_DECL
+#define PHASE_MARK(k)
+#define PHASE_FLUSH
+#endif
+
+constexpr int SC_THREADS = 1024;
+constexpr int STAGE = 512;                  // samples staged per round
 constexpr int HASH_BITS = 13;
-constexpr int HASH_CAP = 1 << HASH_BITS;   // slots
+constexpr int HASH_CAP = 1 << HASH_BITS;    // slots
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-constexpr int WINDOW_BUDGET = 448;          // samples per window to start with (~16 keys/sample)
-constexpr int MAX_PROBES = 192;
+constexpr uint32_t KEY_MASK = 0x00FFFFFFu;
+constexpr int WINDOW_BUDGET = 288;          // samples per window to start with (~15 keys/sample)
+constexpr int MAX_PROBES = 96;              // probe length at which a window is declared too full
 constexpr int MESH = ATTPC_MESH_STEPS;
 constexpr int PIXELS = MESH * MESH;
 
-
 struct __align__(16) ScatterShared {
-  unsigned long long chg[HASH_CAP];
+  double chg[HASH_CAP];       // whole-number charges: exact in f64
   uint32_t keys[HASH_CAP];
-  double st_xlo[SC_THREADS], st_xhi[SC_THREADS], st_ylo[SC_THREADS], st_yhi[SC_THREADS];
-  double st_sx[SC_THREADS], st_sy[SC_THREADS], st_n[SC_THREADS];
-  int st_tb[SC_THREADS];   // bit 31 set => zero-diffusion point transport
   double wtab[PIXELS];
-  int hist[ATTPC_NUM_TB];
-  int win_a, win_b, budget, n_stage, overflow, done, failed, retried;
-  unsigned int wg_cursor, n_rows;
+  double st_n[STAGE];
+  short st_ix[STAGE][MESH];   // LUT row index of mesh line i, -1 = off the pad plane
+  short st_iy[STAGE][MESH];
+  int st_tb[STAGE];           // bits 0..9 time bucket, 24..26 position in `indices`, 30 point transport
+  int blocks[ATTPC_MAX_SIM][MAX_BLOCKS_PER_TRACK];  // arena block ids of the event's tracks
+  int cnt[ATTPC_MAX_SIM + 1]; // exclusive prefix of kept samples per simulated nucleus
+  int cum[ATTPC_NUM_TB];      // inclusive prefix sum of kept samples per time bucket
+  int wave_sum[SC_THREADS / 64];
+  int win_a, win_b, win_samples, budget, n_stage, overflow, done, failed, retried;
+  unsigned int wg_cursor;
   unsigned long long base;
   unsigned long long charge_sum, key_sum;
 };
 
-__device__ __forceinline__ const double* sample_ptr(const TrackBuffers& trk, uint32_t track, int s) {
-  const int blk = trk.block_table[(size_t)track * MAX_BLOCKS_PER_TRACK + (s / ARENA_BLK)];
-  return trk.arena + ((size_t)blk * ARENA_BLK + (s & (ARENA_BLK - 1))) * 4;
+// sample c of the event's concatenated tracks -> record pointer and position in `indices`
+__device__ __forceinline__ const double* sample_ptr(const ScatterShared& sh, const double* arena, int n_sim, int c,
+                                                    int& isim) {
+  isim = 0;
+#pragma unroll
+  for (int k = 1; k < ATTPC_MAX_SIM; ++k)
+    if (k < n_sim && c >= sh.cnt[k]) isim = k;
+  const int s = c - sh.cnt[isim];
+  const int blk = sh.blocks[isim][s / ARENA_BLK];
+  return arena + ((size_t)blk * ARENA_BLK + (s & (ARENA_BLK - 1))) * 4;
 }
 
 __device__ __forceinline__ void clear_table(ScatterShared& sh) {
   for (int i = threadIdx.x; i < HASH_CAP; i += SC_THREADS) {
     sh.keys[i] = EMPTY;
-    sh.chg[i] = 0ull;
+    sh.chg[i] = 0.0;
   }
+}
+
+// first index in [lo, hi) with cum[i] > value (cum nondecreasing)
+__device__ __forceinline__ int upper_bound(const int* cum, int lo, int hi, int value) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cum[mid] > value) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ uint32_t hash_slot(uint32_t key) { return (key * 2654435761u) >> (32 - HASH_BITS); }
+
+// points[key] = (charge + q, label) of transporter.py:247-249 for one pixel: find or claim the
+// key's slot, raise the label, add the charge.  False if the table is too full.
+__device__ __forceinline__ bool pixel_add(ScatterShared& sh, uint32_t key, uint32_t want, double q) {
+  uint32_t h = hash_slot(key);
+  for (int probes = 0; probes < MAX_PROBES; ++probes) {
+    uint32_t cur = sh.keys[h];
+    if (cur == EMPTY) cur = atomicCAS(&sh.keys[h], EMPTY, want);
+    if (cur == EMPTY || (cur & KEY_MASK) == key) {
+      if (cur != EMPTY && cur < want) atomicMax(&sh.keys[h], want);
+      if (q != 0.0) unsafeAtomicAdd(&sh.chg[h], q);
+      return true;
+    }
+    h = (h + 1) & (HASH_CAP - 1);
+  }
+  return false;
 }
 
 __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
   __shared__ ScatterShared sh;
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const uint32_t e_local = blockIdx.x;
   const uint64_t event = a.first_event + e_local;
   const int n_sim = a.layout.n_sim;
   const uint32_t track0 = e_local * (uint32_t)n_sim;
+  const int lut_n = a.det.lut_n, lut_lo = a.det.lut_lo;
+  const int16_t* __restrict__ lut = a.det.pad_lut;
+  const double* __restrict__ arena = a.trk.arena;
 
+  PHASE_DECL;
   // ---- init ----
   for (int p = tid; p < PIXELS; p += SC_THREADS) {
     const double di = (double)(p / MESH) - 4.5, dj = (double)(p % MESH) - 4.5;
     sh.wtab[p] = (36.0 / 81.0) / TWO_PI * exp(-(2.0 / 9.0) * (di * di + dj * dj));
   }
-  for (int i = tid; i < ATTPC_NUM_TB; i += SC_THREADS) sh.hist[i] = 0;
-  clear_table(sh);
+  for (int i = tid; i < ATTPC_NUM_TB; i += SC_THREADS) sh.cum[i] = 0;
   if (tid == 0) {
+    int acc = 0;
+    for (int k = 0; k < n_sim; ++k) {
+      sh.cnt[k] = acc;
+      acc += a.trk.counts[track0 + k];
+    }
+    for (int k = n_sim; k <= ATTPC_MAX_SIM; ++k) sh.cnt[k] = acc;
     sh.win_a = 0; sh.win_b = 0; sh.budget = WINDOW_BUDGET; sh.overflow = 0; sh.done = 0;
-    sh.failed = 0; sh.retried = 0; sh.charge_sum = 0ull; sh.key_sum = 0ull; sh.n_rows = 0u;
+    sh.failed = 0; sh.retried = 0; sh.charge_sum = 0ull; sh.key_sum = 0ull;
+  }
+  clear_table(sh);
+  __syncthreads();
+  const int total = sh.cnt[ATTPC_MAX_SIM];
+  for (int i = tid; i < n_sim * MAX_BLOCKS_PER_TRACK; i += SC_THREADS) {
+    const int k = i / MAX_BLOCKS_PER_TRACK, b = i - k * MAX_BLOCKS_PER_TRACK;
+    const int n_blk = (sh.cnt[k + 1] - sh.cnt[k] + ARENA_BLK - 1) / ARENA_BLK;
+    sh.blocks[k][b] = b < n_blk ? a.trk.block_table[(size_t)(track0 + k) * MAX_BLOCKS_PER_TRACK + b] : 0;
   }
   __syncthreads();
+  PHASE_MARK(0);
 
-  // ---- histogram of kept samples per time bucket (all nuclei) ----
-  unsigned int my_samples = 0;
-  for (int isim = 0; isim < n_sim; ++isim) {
-    const uint32_t track = track0 + (uint32_t)isim;
-    const int cnt = a.trk.counts[track];
-    for (int s = tid; s < cnt; s += SC_THREADS) {
-      const double t = sample_ptr(a.trk, track, s)[2];
-      my_samples++;
-      if (t >= 0.0 && t < (double)ATTPC_NUM_TB) atomicAdd(&sh.hist[(int)t], 1);
-      // t < 0 (sigma_t would be NaN: undefined in the reference) and tb >= 512 (dropped by the
-      // 0 <= tb < 512 mask of simulator.py:111-113) never reach the output
+  // ---- histogram of kept samples per time bucket (all nuclei), then its prefix sum ----
+  for (int c = tid; c < total; c += SC_THREADS) {
+    int isim;
+    const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
+    // t < 0 (sigma_t would be NaN: undefined in the reference) and tb >= 512 (removed by the
+    // 0 <= tb < 512 mask of simulator.py:111-113) never reach the output
+    if (t >= 0.0 && t < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)t], 1);
+  }
+  __syncthreads();
+  {
+    int v = tid < ATTPC_NUM_TB ? sh.cum[tid] : 0;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(v, off);
+      if (lane >= off) v += up;
     }
+    if (lane == 63) sh.wave_sum[tid >> 6] = v;
+    __syncthreads();
+    int offset = 0;
+    for (int w = 0; w < (tid >> 6); ++w) offset += sh.wave_sum[w];
+    if (tid < ATTPC_NUM_TB) sh.cum[tid] = v + offset;
   }
   __syncthreads();
 
   unsigned long long my_charge = 0ull, my_keys = 0ull;
+  PHASE_MARK(1);
 
   for (;;) {
     // ---- choose the next window [win_a, win_b) of time buckets ----
     if (tid == 0) {
-      int a0 = sh.win_b;
-      if (sh.overflow) {  // retry the same start with half the samples
-        a0 = sh.win_a;
-        sh.overflow = 0;
-      }
-      while (a0 < ATTPC_NUM_TB && sh.hist[a0] == 0) a0++;
+      const int from = sh.overflow ? sh.win_a : sh.win_b;  // overflow: same start, smaller budget
+      sh.overflow = 0;
+      const int before = from > 0 ? sh.cum[from - 1] : 0;
+      const int a0 = upper_bound(sh.cum, from, ATTPC_NUM_TB, before);
       if (a0 >= ATTPC_NUM_TB) {
         sh.done = 1;
       } else {
-        int b0 = a0, cum = 0;
-        do { cum += sh.hist[b0]; b0++; } while (b0 < ATTPC_NUM_TB && cum + sh.hist[b0] <= sh.budget);
+        int b0 = upper_bound(sh.cum, a0, ATTPC_NUM_TB, before + sh.budget);
+        if (b0 <= a0) b0 = a0 + 1;
         sh.win_a = a0;
         sh.win_b = b0;
-        sh.n_stage = cum;  // samples in this window (for the budget update on overflow)
+        sh.win_samples = sh.cum[b0 - 1] - before;
       }
     }
     __syncthreads();
     if (sh.done) break;
     const int win_a = sh.win_a, win_b = sh.win_b;
-    const int win_samples = sh.n_stage;
-    __syncthreads();
+    PHASE_MARK(2);
 
-    // ---- scatter every nucleus, in `indices` order ----
-    for (int isim = 0; isim < n_sim; ++isim) {
-      const uint32_t track = track0 + (uint32_t)isim;
-      const int cnt = a.trk.counts[track];
-      for (int base = 0; base < cnt; base += SC_THREADS) {
-        if (tid == 0) sh.n_stage = 0;
-        __syncthreads();
-        const int s = base + tid;
-        if (s < cnt) {
-          const double* rec = sample_ptr(a.trk, track, s);
-          const double2 xy = reinterpret_cast<const double2*>(rec)[0];
-          const double2 tn = reinterpret_cast<const double2*>(rec)[1];
-          const double t = tn.x;
-          if (t >= 0.0 && t < (double)ATTPC_NUM_TB) {
-            const int tb = (int)t;  // transporter.py:238
-            if (tb >= win_a && tb < win_b) {
-              const int slot = atomicAdd(&sh.n_stage, 1);
-              // transporter.py:301
-              const double sigma = sqrt(2.0 * a.det.diffusion * a.det.dv * t / a.det.efield);
-              const double xlo = xy.x - 3.0 * sigma, xhi = xy.x + 3.0 * sigma;
-              const double ylo = xy.y - 3.0 * sigma, yhi = xy.y + 3.0 * sigma;
-              sh.st_xlo[slot] = xlo; sh.st_xhi[slot] = xhi;
-              sh.st_ylo[slot] = ylo; sh.st_yhi[slot] = yhi;
-              sh.st_sx[slot] = (xhi - xlo) / (double)(MESH - 1);  // numpy.linspace step
-              sh.st_sy[slot] = (yhi - ylo) / (double)(MESH - 1);
-              sh.st_n[slot] = tn.y;
-              sh.st_tb[slot] = (sigma == 0.0) ? (tb | (int)0x80000000) : tb;
+    // ---- scatter the window's samples of all nuclei ----
+    for (int base = 0; base < total; base += STAGE) {
+      if (tid == 0) sh.n_stage = 0;
+      __syncthreads();
+      const int c = base + tid;
+      if (tid < STAGE && c < total) {
+        int isim;
+        const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
+        const double2 tn = reinterpret_cast<const double2*>(rec)[1];
+        const double t = tn.x;
+        if (t >= 0.0 && t < (double)ATTPC_NUM_TB) {
+          const int tb = (int)t;  // transporter.py:238
+          if (tb >= win_a && tb < win_b) {
+            const double2 xy = reinterpret_cast<const double2*>(rec)[0];
+            const int slot = atomicAdd(&sh.n_stage, 1);
+            const double sigma = sqrt(2.0 * a.det.diffusion * a.det.dv * t / a.det.efield);  // :301
+            const double lo_mm = (double)lut_lo, hi_mm = (double)(lut_lo + lut_n);
+            // numpy.linspace(c - 3 sigma, c + 3 sigma, 10) (:221-227) and position_to_index
+            // (:107-118: whole-mm floor, low edge inclusive, high edge exclusive) per mesh line
+            const double xlo = xy.x - 3.0 * sigma, xhi = xy.x + 3.0 * sigma;
+            const double ylo = xy.y - 3.0 * sigma, yhi = xy.y + 3.0 * sigma;
+            const double sx = (xhi - xlo) / (double)(MESH - 1), sy = (yhi - ylo) / (double)(MESH - 1);
+#pragma unroll
+            for (int i = 0; i < MESH; ++i) {
+              const double x = (i == MESH - 1) ? xhi : (double)i * sx + xlo;
+              const double y = (i == MESH - 1) ? yhi : (double)i * sy + ylo;
+              const double fx = floor(x * 1000.0), fy = floor(y * 1000.0);
+              sh.st_ix[slot][i] = (fx >= lo_mm && fx < hi_mm) ? (short)((int)fx - lut_lo) : (short)-1;
+              sh.st_iy[slot][i] = (fy >= lo_mm && fy < hi_mm) ? (short)((int)fy - lut_lo) : (short)-1;
             }
+            sh.st_n[slot] = tn.y;
+            sh.st_tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
           }
-        }
-        __syncthreads();
-        const int n_items = sh.n_stage * PIXELS;
-        const uint32_t label_bits = (uint32_t)isim << 24;
-        for (int item = tid; item < n_items; item += SC_THREADS) {
-          if (sh.overflow) break;
-          const int st = item / PIXELS;
-          const int p = item - st * PIXELS;
-          const int i = p / MESH, j = p - i * MESH;
-          const int tbw = sh.st_tb[st];
-          double x, y, w;
-          if (tbw < 0) {  // point_transport: all electrons straight down (transporter.py:123-169)
-            if (p != 0) continue;
-            x = 0.5 * (sh.st_xlo[st] + sh.st_xhi[st]);
-            y = 0.5 * (sh.st_ylo[st] + sh.st_yhi[st]);
-            w = 1.0;
-          } else {
-            x = (i == MESH - 1) ? sh.st_xhi[st] : (double)i * sh.st_sx[st] + sh.st_xlo[st];
-            y = (j == MESH - 1) ? sh.st_yhi[st] : (double)j * sh.st_sy[st] + sh.st_ylo[st];
-            w = sh.wtab[p];
-          }
-          // position_to_index, transporter.py:107-118 (whole-mm floor, low inclusive, high exclusive)
-          const double fx = floor(x * 1000.0), fy = floor(y * 1000.0);
-          const double lo = (double)a.det.lut_lo, hi = (double)(a.det.lut_lo + a.det.lut_n);
-          if (!(fx >= lo && fx < hi && fy >= lo && fy < hi)) continue;
-          const int ix = (int)fx - a.det.lut_lo, iy = (int)fy - a.det.lut_lo;
-          const int pad = a.det.pad_lut[ix * a.det.lut_n + iy];
-          if (pad < 0) continue;  // no pad, or a beam pad (folded)
-          const unsigned long long q = (unsigned long long)(long long)(w * sh.st_n[st]);  // transporter.py:240-246
-          const uint32_t key = ((uint32_t)(tbw & 0x3ff) << 14) | (uint32_t)pad;
-          const uint32_t want = key | label_bits;
-          uint32_t hslot = (key * 2654435761u) >> (32 - HASH_BITS);
-          int probes = 0;
-          for (;;) {
-            const uint32_t cur = sh.keys[hslot];
-            if ((cur & 0x00FFFFFFu) == key) {
-              if (cur != want) sh.keys[hslot] = want;  // last-writer label, transporter.py:249
-              break;
-            }
-            if (cur == EMPTY) {
-              const uint32_t old = atomicCAS(&sh.keys[hslot], EMPTY, want);
-              if (old == EMPTY) break;
-              if ((old & 0x00FFFFFFu) == key) {
-                sh.keys[hslot] = want;
-                break;
-              }
-            }
-            hslot = (hslot + 1) & (HASH_CAP - 1);
-            if (++probes > MAX_PROBES) { sh.overflow = 1; break; }
-          }
-          if (probes <= MAX_PROBES) atomicAdd(&sh.chg[hslot], q);
-        }
-        __syncthreads();
-      }
-    }
-
-    if (sh.overflow) {  // uniform: written before the last barrier
-      clear_table(sh);
-      if (tid == 0) {
-        sh.retried++;
-        if (win_b - win_a <= 1 && win_samples <= 1) {
-          sh.failed = 1;         // a single sample cannot overflow 8192 slots; defensive
-          sh.overflow = 0;
-          sh.win_b = win_a + 1;  // skip this bucket
-        } else if (win_b - win_a <= 1) {
-          sh.failed = 1;         // one time bucket alone exceeds the table: event not representable
-          sh.overflow = 0;
-          sh.win_b = win_a + 1;
-        } else {
-          sh.budget = win_samples / 2 > 0 ? win_samples / 2 : 1;
         }
       }
       __syncthreads();
+      PHASE_MARK(3);
+      const int n_items = sh.n_stage * PIXELS;
+      bool ok = true;
+      for (int item = tid; item < n_items && ok; item += SC_THREADS) {
+        const int st = item / PIXELS;
+        const int p = item - st * PIXELS;
+        const int i = p / MESH, j = p - i * MESH;
+        const int tbw = sh.st_tb[st];
+        double w = sh.wtab[p];
+        if (tbw & (1 << 30)) {
+          // point_transport (transporter.py:123-169): all electrons straight down.  With
+          // sigma == 0 every mesh line sits on the centre: pixel 0 stands for the sample.
+          if (p != 0) continue;
+          w = 1.0;
+        }
+        const int ix = sh.st_ix[st][i], iy = sh.st_iy[st][j];
+        if (ix < 0 || iy < 0) continue;
+        const int pad = lut[ix * lut_n + iy];
+        if (pad < 0) continue;  // no pad there, or a beam pad (folded into the LUT)
+        const double q = trunc(w * sh.st_n[st]);  // int(pdf h^2 n), transporter.py:240-246
+        const uint32_t key = ((uint32_t)(tbw & 0x3ff) << 14) | (uint32_t)pad;
+        ok = pixel_add(sh, key, key | ((uint32_t)((tbw >> 24) & 7) << 24), q);
+      }
+      if (!ok) sh.overflow = 1;
+      __syncthreads();
+      PHASE_MARK(4);
+      if (sh.overflow) break;  // uniform: every thread sees the flag after the barrier
+    }
+
+    if (sh.overflow) {
+      __syncthreads();
+      clear_table(sh);
+      if (tid == 0) {
+        sh.retried++;
+        if (win_b - win_a <= 1) {
+          sh.failed = 1;          // one time bucket alone exceeds the table: not representable
+          sh.overflow = 0;
+          sh.win_b = win_a + 1;   // skip this bucket
+          sh.budget = WINDOW_BUDGET;
+        } else {
+          sh.budget = sh.win_samples / 2 > 0 ? sh.win_samples / 2 : 1;
+        }
+      }
+      __syncthreads();
+      PHASE_MARK(5);
       continue;
     }
 
@@ -236,32 +307,35 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     unsigned int mine = 0;
     for (int i = tid; i < HASH_CAP; i += SC_THREADS) mine += (sh.keys[i] != EMPTY) ? 1u : 0u;
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-    if ((tid & 63) == 0 && mine) atomicAdd(&sh.wg_cursor, mine);
+    if (lane == 0 && mine) atomicAdd(&sh.wg_cursor, mine);
     __syncthreads();
-    const unsigned int total = sh.wg_cursor;
+    const unsigned int n_rows = sh.wg_cursor;
     __syncthreads();
     if (tid == 0) {
       sh.wg_cursor = 0u;
       unsigned long long base = 0ull;
-      if (total) {
-        base = atomicAdd(&a.out.ctrl[0], (unsigned long long)total);
+      if (n_rows) {
+        base = atomicAdd(&a.out.ctrl[0], (unsigned long long)n_rows);
         const unsigned long long si = atomicAdd(&a.out.ctrl[1], 1ull);
-        if (base + total > (unsigned long long)a.out.capacity || si >= (unsigned long long)a.out.seg_capacity) {
+        if (base + n_rows > (unsigned long long)a.out.capacity || si >= (unsigned long long)a.out.seg_capacity) {
           a.out.ctrl[6] = 1ull;  // out of capacity: host re-runs the chunk with larger buffers
           base = ~0ull;
         } else {
           Segment sg;
           sg.event = (int32_t)e_local;
-          sg.count = (int32_t)total;
+          sg.count = (int32_t)n_rows;
           sg.offset = (int64_t)base;
           a.out.segments[si] = sg;
         }
       }
       sh.base = base;
-      sh.n_rows += total;
-      sh.budget = WINDOW_BUDGET;
+      // adapt: aim at half-full tables (keys per sample varies with track geometry)
+      const int per_sample_x16 = sh.win_samples > 0 ? (int)(n_rows * 16u) / sh.win_samples : 0;
+      sh.budget = per_sample_x16 > 0 ? (HASH_CAP / 2) * 16 / per_sample_x16 : WINDOW_BUDGET;
+      if (sh.budget < 32) sh.budget = 32;
     }
     __syncthreads();
+    PHASE_MARK(6);
     const unsigned long long base = sh.base;
     for (int i0 = 0; i0 < HASH_CAP; i0 += SC_THREADS) {
       const int i = i0 + tid;
@@ -269,44 +343,45 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
       const bool occ = word != EMPTY;
       const unsigned long long m = __ballot(occ);
       unsigned int wbase = 0;
-      if ((tid & 63) == 0 && m) wbase = atomicAdd(&sh.wg_cursor, (unsigned int)__popcll(m));
+      if (lane == 0 && m) wbase = atomicAdd(&sh.wg_cursor, (unsigned int)__popcll(m));
       wbase = __shfl(wbase, 0);
       if (occ) {
-        const unsigned long long q = sh.chg[i];
+        const double q = sh.chg[i];
         sh.keys[i] = EMPTY;
-        sh.chg[i] = 0ull;
-        const uint32_t key = word & 0x00FFFFFFu;
+        sh.chg[i] = 0.0;
+        const uint32_t key = word & KEY_MASK;
         const int pad = (int)(key & 0x3fffu), tb = (int)(key >> 14);
-        my_charge += q;
+        my_charge += (unsigned long long)q;
         my_keys += (event << 24) + (unsigned long long)key;
         if (base != ~0ull) {
-          const unsigned long long row = base + wbase + (unsigned int)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+          const unsigned long long row = base + wbase + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
           double ua, ub;
           rng_pair(a.seed, event, key, DOMAIN_JITTER, ua, ub);  // simulator.py:108
           double* o = a.out.points + row * 3;
           o[0] = (double)pad;
           o[1] = (double)tb + ua;
-          o[2] = (double)(long long)q;
+          o[2] = q;
           a.out.labels[row] = (int64_t)a.layout.indices[word >> 24];
         }
       }
     }
     __syncthreads();
+    PHASE_MARK(7);
   }
+  PHASE_FLUSH;
 
   // ---- per-event statistics ----
   for (int off = 32; off > 0; off >>= 1) {
     my_charge += __shfl_down(my_charge, off);
     my_keys += __shfl_down(my_keys, off);
-    my_samples += __shfl_down(my_samples, off);
   }
-  if ((tid & 63) == 0) {
-    atomicAdd(&sh.charge_sum, my_charge);
-    atomicAdd(&sh.key_sum, my_keys);
-    if (my_samples) atomicAdd(&a.out.ctrl[7], (unsigned long long)my_samples);
+  if (lane == 0) {
+    if (my_charge) atomicAdd(&sh.charge_sum, my_charge);
+    if (my_keys) atomicAdd(&sh.key_sum, my_keys);
   }
   __syncthreads();
   if (tid == 0) {
+    if (total) atomicAdd(&a.out.ctrl[7], (unsigned long long)total);
     if (sh.charge_sum) atomicAdd(&a.out.ctrl[2], sh.charge_sum);
     if (sh.key_sum) atomicAdd(&a.out.ctrl[3], sh.key_sum);
     if (sh.failed) atomicAdd(&a.out.ctrl[4], 1ull);

@@ -7,14 +7,19 @@
 // :78-120 (position_to_index: floor to whole mm), pairing.py (key), beam_pads.py (folded
 // into the LUT), simulator.py:19-49 (dict_to_points), :108-113 (tb jitter, 0 <= tb < 512).
 //
-// Execution model: one workgroup = one event.  The event's dictionary is an open-addressing
-// hash table in LDS (u32 key|label word + f64 charge, 8192 slots = 96 KiB).  Staging: one lane
-// per kept track sample computes sigma_t and the whole-mm LUT indices of the sample's 10 mesh
-// columns and 10 mesh rows (20 floors instead of 200) into LDS.  Work item = one mesh pixel:
-// two LDS index reads, one 2-byte gather from the 625 KB pad LUT (L2 resident), one f64
-// multiply + truncate, one hash insert (ds_read probe, ds_cmpst_b32 to claim a slot,
-// ds_max_u32 for the label) and one ds_add_f64 of the charge.  Pixel charges are whole
-// numbers far below 2^53, so f64 accumulation is exact and order independent.
+// Execution model: one workgroup = one event; its dictionary is an open-addressing hash table
+// in LDS (u32 key|label word + f64 charge, 8192 slots = 96 KiB).  Per round:
+//   stage  (workgroup) one lane per kept track sample: sigma_t and the whole-mm LUT indices
+//          of the sample's 10 mesh columns / 10 mesh rows (20 floors instead of 200) -> LDS
+//   rows   (per wave, no workgroup barrier) one lane per mesh row: 10 pad look-ups in flight
+//          (2-byte gathers from the 625 KB LUT, L2 resident), truncate the 10 pixel charges,
+//          merge runs of equal pads in registers, write the runs (key|label, charge) to the
+//          wave's queue in LDS at positions from a wave prefix sum
+//   insert (same wave) one lane per queued run, all lanes busy: ds_read probe, ds_cmpst_b32
+//          to claim a slot, ds_max_u32 for the label, ds_add_f64 for the charge
+// Merging before inserting cuts hash inserts ~7x (100 pixels -> ~15 pads per sample) and the
+// queue turns the sparse "which lanes end a run" pattern into dense wave work.  Pixel charges
+// are whole numbers far below 2^53, so f64 accumulation is exact and order independent.
 // Events with more keys than the table holds are cut into time-bucket windows (a key
 // contains its time bucket, so windows partition the key space; boundaries come from a
 // prefix sum of the per-bucket sample histogram); each window is flushed as one contiguous
@@ -26,7 +31,7 @@
 // pdf(pixel) h^2 depends only on the pixel index: (36/81)/(2 pi) exp(-(2/9)((i-4.5)^2+(j-4.5)^2))
 // because the mesh pitch is h = 6 sigma / 9; the 100 weights are a constant table.
 //
-// Bound: LDS atomics + LUT gathers + f64 VALU; HBM traffic is the 32 B per output row
+// Bound: VALU/SALU issue + LDS atomics + LUT gathers; HBM traffic is the 32 B per output row
 // (3 f64 + i64, the reference's own dtypes) and 32 B per track sample read.
 #include "tracks_args.hpp"
 
@@ -54,19 +59,24 @@ namespace attpc {
 #endif
 
 constexpr int SC_THREADS = 1024;
-constexpr int STAGE = 512;                  // samples staged per round
+constexpr int STAGE = 320;                  // samples examined per round
 constexpr int HASH_BITS = 13;
 constexpr int HASH_CAP = 1 << HASH_BITS;    // slots
+constexpr int WAVE_QUEUE = 256;             // queued runs per wave and pass (typ. ~190 per 64 mesh rows)
+constexpr int N_WAVES = SC_THREADS / 64;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;
-constexpr int WINDOW_BUDGET = 288;          // samples per window to start with (~15 keys/sample)
+constexpr int WINDOW_BUDGET = HASH_CAP / 28; // samples per window to start with (~14 keys/sample, half full)
 constexpr int MAX_PROBES = 96;              // probe length at which a window is declared too full
 constexpr int MESH = ATTPC_MESH_STEPS;
 constexpr int PIXELS = MESH * MESH;
+static_assert(SC_THREADS >= ATTPC_NUM_TB, "prefix sum uses one thread per time bucket");
+static_assert(2 * N_WAVES * WAVE_QUEUE >= HASH_CAP, "the wave queues double as the slot list of a flush");
 
 struct __align__(16) ScatterShared {
   double chg[HASH_CAP];       // whole-number charges: exact in f64
-  uint32_t keys[HASH_CAP];
+  uint32_t keys[HASH_CAP];    // bits 0..13 pad, 14..23 time bucket, 24..26 position in `indices`
+  uint32_t queue[N_WAVES][2][WAVE_QUEUE];  // per wave: [0][k] = key|label, [1][k] = charge; slot list during a flush
   double wtab[PIXELS];
   double st_n[STAGE];
   short st_ix[STAGE][MESH];   // LUT row index of mesh line i, -1 = off the pad plane
@@ -112,21 +122,26 @@ __device__ __forceinline__ int upper_bound(const int* cum, int lo, int hi, int v
 
 __device__ __forceinline__ uint32_t hash_slot(uint32_t key) { return (key * 2654435761u) >> (32 - HASH_BITS); }
 
-// points[key] = (charge + q, label) of transporter.py:247-249 for one pixel: find or claim the
-// key's slot, raise the label, add the charge.  False if the table is too full.
-__device__ __forceinline__ bool pixel_add(ScatterShared& sh, uint32_t key, uint32_t want, double q) {
+// points[key] = (charge + q, label) of transporter.py:247-249: find or claim the key's slot,
+// raise the label, add the charge.  `want` = key | label bits.  False if the table is too full.
+__device__ __forceinline__ bool table_add(ScatterShared& sh, uint32_t want, double q) {
+  const uint32_t key = want & KEY_MASK;
   uint32_t h = hash_slot(key);
-  for (int probes = 0; probes < MAX_PROBES; ++probes) {
-    uint32_t cur = sh.keys[h];
-    if (cur == EMPTY) cur = atomicCAS(&sh.keys[h], EMPTY, want);
-    if (cur == EMPTY || (cur & KEY_MASK) == key) {
-      if (cur != EMPTY && cur < want) atomicMax(&sh.keys[h], want);
-      if (q != 0.0) unsafeAtomicAdd(&sh.chg[h], q);
-      return true;
+  uint32_t cur = sh.keys[h];
+  if ((cur & KEY_MASK) != key) {  // not at its home slot: claim it or walk the probe sequence
+    int probes = 0;
+    for (;;) {
+      if (cur == EMPTY) cur = atomicCAS(&sh.keys[h], EMPTY, want);
+      if (cur == EMPTY) { cur = want; break; }
+      if ((cur & KEY_MASK) == key) break;
+      if (++probes >= MAX_PROBES) return false;
+      h = (h + 1) & (HASH_CAP - 1);
+      cur = sh.keys[h];
     }
-    h = (h + 1) & (HASH_CAP - 1);
   }
-  return false;
+  if (cur < want) atomicMax(&sh.keys[h], want);
+  unsafeAtomicAdd(&sh.chg[h], q);
+  return true;
 }
 
 __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
@@ -217,10 +232,11 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     const int win_a = sh.win_a, win_b = sh.win_b;
     PHASE_MARK(2);
 
-    // ---- scatter the window's samples of all nuclei ----
+    // ---- scatter the window's samples of all nuclei, STAGE samples per round ----
     for (int base = 0; base < total; base += STAGE) {
       if (tid == 0) sh.n_stage = 0;
       __syncthreads();
+      // stage
       const int c = base + tid;
       if (tid < STAGE && c < total) {
         int isim;
@@ -254,27 +270,83 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
       }
       __syncthreads();
       PHASE_MARK(3);
-      const int n_items = sh.n_stage * PIXELS;
+
+      // rows -> runs -> this wave's queue -> table, 64 mesh rows per wave at a time
       bool ok = true;
-      for (int item = tid; item < n_items && ok; item += SC_THREADS) {
-        const int st = item / PIXELS;
-        const int p = item - st * PIXELS;
-        const int i = p / MESH, j = p - i * MESH;
-        const int tbw = sh.st_tb[st];
-        double w = sh.wtab[p];
-        if (tbw & (1 << 30)) {
+      {
+        const int n_rows = sh.n_stage * MESH;
+        const int wave = tid >> 6;
+        uint32_t* __restrict__ q_key = sh.queue[wave][0];
+        uint32_t* __restrict__ q_chg = sh.queue[wave][1];
+        for (int row0 = wave * 64; row0 < n_rows; row0 += SC_THREADS) {  // wave-uniform trip count
+          const int row = row0 + lane;
+          const bool have = row < n_rows;
+          const int st = have ? row / MESH : 0;
+          const int i = have ? row - st * MESH : 0;
+          const int tbw = sh.st_tb[st];
+          const bool point = (tbw & (1 << 30)) != 0;
+          const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
+          const double n_el = sh.st_n[st];
+          const int ix = sh.st_ix[st][i];
           // point_transport (transporter.py:123-169): all electrons straight down.  With
-          // sigma == 0 every mesh line sits on the centre: pixel 0 stands for the sample.
-          if (p != 0) continue;
-          w = 1.0;
+          // sigma == 0 every mesh line sits on the centre: row 0, pixel 0 stand for the sample.
+          const bool live = have && ix >= 0 && (!point || i == 0);
+          int raw[MESH];
+          const int16_t* __restrict__ lut_row = lut + (live ? ix : 0) * lut_n;
+#pragma unroll
+          for (int j = 0; j < MESH; ++j) {  // 10 independent gathers in flight
+            const int iy = sh.st_iy[st][j];
+            raw[j] = (live && iy >= 0 && (!point || j == 0)) ? (int)lut_row[iy] : -1;
+          }
+          // truncate per pixel (transporter.py:240-246), merge runs of equal pads: a run's
+          // total sits with its last pixel
+          double run_q[MESH];
+          uint32_t ends = 0;  // bit j: pixel j ends a run on a real pad
+          {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < MESH; ++j) {
+              const double w = point ? 1.0 : sh.wtab[i * MESH + j];
+              if (raw[j] >= 0) acc += trunc(w * n_el);
+              const bool last = (j == MESH - 1) || (raw[j < MESH - 1 ? j + 1 : j] != raw[j]);
+              run_q[j] = acc;
+              if (last) {
+                if (raw[j] >= 0) {
+                  if (acc >= 4294967296.0) {  // does not fit the queue's u32: insert directly (rare)
+                    ok = table_add(sh, word_hi | (uint32_t)raw[j], acc) && ok;
+                  } else {
+                    ends |= 1u << j;
+                  }
+                }
+                acc = 0.0;
+              }
+            }
+          }
+          const int n_runs = __popc(ends);
+          int incl = n_runs;  // wave prefix sum -> queue positions
+          for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+          }
+          const int wave_total = __shfl(incl, 63);
+          const int first = incl - n_runs;
+          for (int pass0 = 0; pass0 < wave_total; pass0 += WAVE_QUEUE) {
+            int e = first - pass0;  // queue position of this lane's next run in this pass
+#pragma unroll
+            for (int j = 0; j < MESH; ++j) {
+              if (ends & (1u << j)) {
+                if (e >= 0 && e < WAVE_QUEUE) {
+                  q_key[e] = word_hi | (uint32_t)raw[j];
+                  q_chg[e] = (uint32_t)run_q[j];
+                }
+                e++;
+              }
+            }
+            const int n_q = min(wave_total - pass0, WAVE_QUEUE);
+            for (int k = lane; k < n_q && ok; k += 64) ok = table_add(sh, q_key[k], (double)q_chg[k]);
+          }
+          if (__any(!ok)) break;  // table too full: the whole wave stops together (shuffles above)
         }
-        const int ix = sh.st_ix[st][i], iy = sh.st_iy[st][j];
-        if (ix < 0 || iy < 0) continue;
-        const int pad = lut[ix * lut_n + iy];
-        if (pad < 0) continue;  // no pad there, or a beam pad (folded into the LUT)
-        const double q = trunc(w * sh.st_n[st]);  // int(pdf h^2 n), transporter.py:240-246
-        const uint32_t key = ((uint32_t)(tbw & 0x3ff) << 14) | (uint32_t)pad;
-        ok = pixel_add(sh, key, key | ((uint32_t)((tbw >> 24) & 7) << 24), q);
       }
       if (!ok) sh.overflow = 1;
       __syncthreads();
@@ -297,22 +369,24 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
         }
       }
       __syncthreads();
-      PHASE_MARK(5);
       continue;
     }
 
-    // ---- flush: count, reserve one contiguous range, write rows, clear ----
+    // ---- flush: compact the occupied slots, reserve one contiguous range, write rows ----
     if (tid == 0) sh.wg_cursor = 0u;
     __syncthreads();
-    unsigned int mine = 0;
-    for (int i = tid; i < HASH_CAP; i += SC_THREADS) mine += (sh.keys[i] != EMPTY) ? 1u : 0u;
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-    if (lane == 0 && mine) atomicAdd(&sh.wg_cursor, mine);
+    for (int i0 = 0; i0 < HASH_CAP; i0 += SC_THREADS) {
+      const int i = i0 + tid;
+      const bool occ = sh.keys[i] != EMPTY;
+      const unsigned long long m = __ballot(occ);
+      unsigned int wbase = 0;
+      if (lane == 0 && m) wbase = atomicAdd(&sh.wg_cursor, (unsigned int)__popcll(m));
+      wbase = __shfl(wbase, 0);
+      if (occ) (&sh.queue[0][0][0])[wbase + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    }
     __syncthreads();
     const unsigned int n_rows = sh.wg_cursor;
-    __syncthreads();
     if (tid == 0) {
-      sh.wg_cursor = 0u;
       unsigned long long base = 0ull;
       if (n_rows) {
         base = atomicAdd(&a.out.ctrl[0], (unsigned long long)n_rows);
@@ -337,32 +411,25 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     __syncthreads();
     PHASE_MARK(6);
     const unsigned long long base = sh.base;
-    for (int i0 = 0; i0 < HASH_CAP; i0 += SC_THREADS) {
-      const int i = i0 + tid;
-      const uint32_t word = sh.keys[i];
-      const bool occ = word != EMPTY;
-      const unsigned long long m = __ballot(occ);
-      unsigned int wbase = 0;
-      if (lane == 0 && m) wbase = atomicAdd(&sh.wg_cursor, (unsigned int)__popcll(m));
-      wbase = __shfl(wbase, 0);
-      if (occ) {
-        const double q = sh.chg[i];
-        sh.keys[i] = EMPTY;
-        sh.chg[i] = 0.0;
-        const uint32_t key = word & KEY_MASK;
-        const int pad = (int)(key & 0x3fffu), tb = (int)(key >> 14);
-        my_charge += (unsigned long long)q;
-        my_keys += (event << 24) + (unsigned long long)key;
-        if (base != ~0ull) {
-          const unsigned long long row = base + wbase + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-          double ua, ub;
-          rng_pair(a.seed, event, key, DOMAIN_JITTER, ua, ub);  // simulator.py:108
-          double* o = a.out.points + row * 3;
-          o[0] = (double)pad;
-          o[1] = (double)tb + ua;
-          o[2] = q;
-          a.out.labels[row] = (int64_t)a.layout.indices[word >> 24];
-        }
+    for (unsigned int r = tid; r < n_rows; r += SC_THREADS) {
+      const uint32_t slot = (&sh.queue[0][0][0])[r];
+      const uint32_t word = sh.keys[slot];
+      const double q = sh.chg[slot];
+      sh.keys[slot] = EMPTY;
+      sh.chg[slot] = 0.0;
+      const uint32_t key = word & KEY_MASK;
+      const int pad = (int)(key & 0x3fffu), tb = (int)(key >> 14);
+      my_charge += (unsigned long long)q;
+      my_keys += (event << 24) + (unsigned long long)key;
+      if (base != ~0ull) {
+        const unsigned long long row = base + r;
+        double ua, ub;
+        rng_pair(a.seed, event, key, DOMAIN_JITTER, ua, ub);  // simulator.py:108
+        double* o = a.out.points + row * 3;
+        o[0] = (double)pad;
+        o[1] = (double)tb + ua;
+        o[2] = q;
+        a.out.labels[row] = (int64_t)a.layout.indices[word >> 24];
       }
     }
     __syncthreads();

@@ -97,6 +97,7 @@ def main() -> None:
     events_per_launch = n_events * args.steps / launches
     avg_ms = agg[ms_key] / launches
     achieved = events_per_launch * bytes_per_event / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic, traffic_note = measured_traffic(args.workload, dominant, events_per_launch)
     line = {
         "metric": "events/sec (whole node); 2-step reaction + full detector batch",
         "value": value,
@@ -131,7 +132,10 @@ def main() -> None:
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_unit": "bytes per launch",
+            "traffic_source": traffic_note,
+            "algorithmic_bytes_per_launch": events_per_launch * bytes_per_event,
             "avg_launch_ms": avg_ms,
             "events_per_launch": events_per_launch,
             "kernel_ms_total": {k: agg[v[0]] for k, v in kernels.items()} | {"kin_run_kernel": agg["ms_kinematics"]},
@@ -141,6 +145,20 @@ def main() -> None:
     if world_size == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
     print(json.dumps(line), flush=True)
+
+
+def measured_traffic(workload: str, kernel: str, events_per_launch: float):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE +
+    WRITE_SIZE, KiB -> bytes; see profiles/r01_hbm_traffic.json for the correction notes),
+    scaled from the profiled launch size to this run's.  None when no profile exists."""
+    path = ROOT / "profiles" / "r01_hbm_traffic.json"
+    try:
+        prof = json.loads(path.read_text())[workload]
+        k = prof[kernel]
+        per_event = (k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0 / prof["events_per_launch"]
+        return per_event * events_per_launch, f"profiles/{path.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH uncorrected)"
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC profile for this workload"
 
 
 def cpu_baseline(workload: str, seed: int) -> dict:

@@ -54,7 +54,8 @@ def main() -> None:
     dist = sharding.init_process_group("gloo")  # control plane only: barrier + scalar reductions
 
     pipeline, config, indices = workloads.WORKLOADS[args.workload](seed=args.seed)
-    ctx = _abi.Context(local_rank)
+    n_dev = max(1, _abi.load_library().attpc_device_count())
+    ctx = _abi.Context(local_rank % n_dev)  # one rank per GPU; wraps only when rehearsing on fewer GPUs
     engine = Engine(pipeline, config, indices, context=ctx, chunk_events=args.chunk_events or None)
     first, n_events = sharding.weak_shard(args.events, rank)
 

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -130,6 +131,12 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
   size_t want_blocks = std::max<size_t>(ctx->arena_blocks, (size_t)n_tracks * 6 + 1024);
   int64_t want_rows = std::max<int64_t>(ctx->cloud_capacity, (int64_t)n * 9216 + 65536);
   int64_t want_segs = std::max<int64_t>(ctx->seg_capacity, (int64_t)n * 6 + 4096);
+  if (std::getenv("ATTPC_TEST_TINY_BUFFERS") && ctx->arena_blocks == 0) {
+    // test hook: start with buffers that are certainly too small so the grow-and-rerun path runs
+    want_blocks = 4;
+    want_rows = 64;
+    want_segs = 2;
+  }
 
   for (int attempt = 0; attempt < 8; ++attempt) {
     if ((rc = ensure(ctx, ctx->arena, want_blocks * ARENA_BLK * 4 * sizeof(double)))) return rc;
@@ -186,7 +193,7 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 
     uint32_t tctrl[4];
-    unsigned long long octrl[16];
+    unsigned long long octrl[24];
     HIP_TRY(ctx, hipMemcpyAsync(tctrl, ctx->trk_ctrl.p, sizeof tctrl, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(octrl, ctx->out_ctrl.p, sizeof octrl, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -209,6 +216,7 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
 #ifdef ATTPC_PHASE_TIMERS
     fprintf(stderr, "[attpc phase cycles] init %llu hist %llu select %llu stage %llu items %llu overflow %llu flushcount %llu flushwrite %llu (events %u)\n",
             octrl[8], octrl[9], octrl[10], octrl[11], octrl[12], octrl[13], octrl[14], octrl[15], n);
+    fprintf(stderr, "[attpc rows-phase cycles] gathers %llu runs %llu scan+queue %llu drain %llu\n", octrl[16], octrl[17], octrl[18], octrl[19]);
     fprintf(stderr, "[attpc ctrl] rows %llu segments %llu failed %llu retried %llu samples %llu\n", octrl[0], octrl[1],
             octrl[4], octrl[5], octrl[7]);
 #endif

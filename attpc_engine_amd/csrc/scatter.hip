@@ -40,43 +40,55 @@ namespace attpc {
 // Diagnostic build only (-DATTPC_PHASE_TIMERS): thread 0 of every workgroup accumulates
 // s_memtime deltas per phase into out.ctrl[8 + phase]; never compiled into the shipped library.
 #ifdef ATTPC_PHASE_TIMERS
-#define PHASE_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(), ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PHASE_MARK(k)                                               \
   do {                                                              \
     const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); \
     ph_acc[k] += ph_now - ph_t0;                                    \
     ph_t0 = ph_now;                                                 \
   } while (0)
+#define PHASE_SYNC asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #define PHASE_FLUSH                                                          \
   do {                                                                       \
     if (tid == 0)                                                            \
-      for (int k = 0; k < 8; ++k) atomicAdd(&a.out.ctrl[8 + k], ph_acc[k]); \
+      for (int k = 0; k < 12; ++k) atomicAdd(&a.out.ctrl[8 + k], ph_acc[k]); \
   } while (0)
 #else
 #define PHASE_DECL
 #define PHASE_MARK(k)
+#define PHASE_SYNC
 #define PHASE_FLUSH
 #endif
 
-constexpr int SC_THREADS = 1024;
-constexpr int STAGE = 320;                  // samples examined per round
-constexpr int HASH_BITS = 13;
+#ifndef ATTPC_SC_THREADS
+#define ATTPC_SC_THREADS 1024
+#endif
+#ifndef ATTPC_SC_HASH_BITS
+#define ATTPC_SC_HASH_BITS 13
+#endif
+#ifndef ATTPC_SC_STAGE
+#define ATTPC_SC_STAGE 320
+#endif
+constexpr int SC_THREADS = ATTPC_SC_THREADS;
+constexpr int STAGE = ATTPC_SC_STAGE;       // samples examined per round
+constexpr int HASH_BITS = ATTPC_SC_HASH_BITS;
 constexpr int HASH_CAP = 1 << HASH_BITS;    // slots
 constexpr int WAVE_QUEUE = 256;             // queued runs per wave and pass (typ. ~190 per 64 mesh rows)
 constexpr int N_WAVES = SC_THREADS / 64;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;
 constexpr int WINDOW_BUDGET = HASH_CAP / 28; // samples per window to start with (~14 keys/sample, half full)
-constexpr int MAX_PROBES = 96;              // probe length at which a window is declared too full
 constexpr int MESH = ATTPC_MESH_STEPS;
 constexpr int PIXELS = MESH * MESH;
-static_assert(SC_THREADS >= ATTPC_NUM_TB, "prefix sum uses one thread per time bucket");
-static_assert(2 * N_WAVES * WAVE_QUEUE >= HASH_CAP, "the wave queues double as the slot list of a flush");
+constexpr int BINS_PER_THREAD = (ATTPC_NUM_TB + SC_THREADS - 1) / SC_THREADS;
+static_assert(STAGE <= SC_THREADS, "one lane per staged sample");
+static_assert(2 * N_WAVES * (WAVE_QUEUE + 2) >= HASH_CAP, "the wave queues double as the slot list of a flush");
 
 struct __align__(16) ScatterShared {
-  double chg[HASH_CAP];       // whole-number charges: exact in f64
+  unsigned long long chg[HASH_CAP];  // electrons per key (ds_add_u64)
   uint32_t keys[HASH_CAP];    // bits 0..13 pad, 14..23 time bucket, 24..26 position in `indices`
-  uint32_t queue[N_WAVES][2][WAVE_QUEUE];  // per wave: [0][k] = key|label, [1][k] = charge; slot list during a flush
+  uint32_t queue[N_WAVES][2][WAVE_QUEUE + 2];  // per wave: [0][k] = key|label, [1][k] = charge (+ dump slot);
+                                               // the whole array is the slot list during a flush
   double wtab[PIXELS];
   double st_n[STAGE];
   short st_ix[STAGE][MESH];   // LUT row index of mesh line i, -1 = off the pad plane
@@ -107,7 +119,7 @@ __device__ __forceinline__ const double* sample_ptr(const ScatterShared& sh, con
 __device__ __forceinline__ void clear_table(ScatterShared& sh) {
   for (int i = threadIdx.x; i < HASH_CAP; i += SC_THREADS) {
     sh.keys[i] = EMPTY;
-    sh.chg[i] = 0.0;
+    sh.chg[i] = 0ull;
   }
 }
 
@@ -120,27 +132,50 @@ __device__ __forceinline__ int upper_bound(const int* cum, int lo, int hi, int v
   return lo;
 }
 
-__device__ __forceinline__ uint32_t hash_slot(uint32_t key) { return (key * 2654435761u) >> (32 - HASH_BITS); }
+constexpr int BUCKET = 4;                           // keys per bucket = one ds_read_b128
+constexpr int N_BUCKETS = HASH_CAP / BUCKET;
+constexpr int MAX_BUCKET_PROBES = 48;
+
+__device__ __forceinline__ uint32_t hash_bucket(uint32_t key) {
+  return (key * 2654435761u) >> (32 - (HASH_BITS - 2));
+}
 
 // points[key] = (charge + q, label) of transporter.py:247-249: find or claim the key's slot,
-// raise the label, add the charge.  `want` = key | label bits.  False if the table is too full.
-__device__ __forceinline__ bool table_add(ScatterShared& sh, uint32_t want, double q) {
+// raise the label, add the charge.  `want` = key | label bits.  The table is bucketed: one
+// 16-byte LDS read shows 4 candidate slots, so a probe step is one round trip and chains stay
+// short at 50 % load (linear probing over single slots needed ~15 dependent round trips for
+// the slowest of 64 lanes).  False if the table is too full.
+__device__ __forceinline__ bool table_add(ScatterShared& sh, uint32_t want, unsigned long long q) {
   const uint32_t key = want & KEY_MASK;
-  uint32_t h = hash_slot(key);
-  uint32_t cur = sh.keys[h];
-  if ((cur & KEY_MASK) != key) {  // not at its home slot: claim it or walk the probe sequence
-    int probes = 0;
-    for (;;) {
-      if (cur == EMPTY) cur = atomicCAS(&sh.keys[h], EMPTY, want);
-      if (cur == EMPTY) { cur = want; break; }
-      if ((cur & KEY_MASK) == key) break;
-      if (++probes >= MAX_PROBES) return false;
-      h = (h + 1) & (HASH_CAP - 1);
-      cur = sh.keys[h];
+  uint32_t b = hash_bucket(key);
+  uint32_t h = 0, cur = 0;
+  int probes = 0;
+  for (;;) {
+    const uint4 k4 = *reinterpret_cast<const uint4*>(&sh.keys[b * BUCKET]);
+    const bool m0 = (k4.x & KEY_MASK) == key, m1 = (k4.y & KEY_MASK) == key;
+    const bool m2 = (k4.z & KEY_MASK) == key, m3 = (k4.w & KEY_MASK) == key;
+    if (m0 || m1 || m2 || m3) {
+      const uint32_t pos = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : 3u));
+      h = b * BUCKET + pos;
+      cur = m0 ? k4.x : (m1 ? k4.y : (m2 ? k4.z : k4.w));
+      break;
     }
+    const bool e0 = k4.x == EMPTY, e1 = k4.y == EMPTY, e2 = k4.z == EMPTY, e3 = k4.w == EMPTY;
+    if (e0 || e1 || e2 || e3) {  // claim the first free slot of this bucket
+      const uint32_t pos = e0 ? 0u : (e1 ? 1u : (e2 ? 2u : 3u));
+      const uint32_t old = atomicCAS(&sh.keys[b * BUCKET + pos], EMPTY, want);
+      if (old == EMPTY || (old & KEY_MASK) == key) {
+        h = b * BUCKET + pos;
+        cur = old == EMPTY ? want : old;
+        break;
+      }
+      continue;  // lost the slot to another key: look at the bucket again
+    }
+    if (++probes >= MAX_BUCKET_PROBES) return false;
+    b = (b + 1) & (N_BUCKETS - 1);
   }
   if (cur < want) atomicMax(&sh.keys[h], want);
-  unsafeAtomicAdd(&sh.chg[h], q);
+  atomicAdd(&sh.chg[h], q);
   return true;
 }
 
@@ -193,17 +228,29 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     if (t >= 0.0 && t < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)t], 1);
   }
   __syncthreads();
-  {
-    int v = tid < ATTPC_NUM_TB ? sh.cum[tid] : 0;
-    for (int off = 1; off < 64; off <<= 1) {
-      const int up = __shfl_up(v, off);
-      if (lane >= off) v += up;
+  {  // inclusive prefix sum over the 512 buckets: per-thread serial part, wave scan, wave offsets
+    int local[BINS_PER_THREAD];
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < BINS_PER_THREAD; ++k) {
+      const int bin = tid * BINS_PER_THREAD + k;
+      v += bin < ATTPC_NUM_TB ? sh.cum[bin] : 0;
+      local[k] = v;
     }
-    if (lane == 63) sh.wave_sum[tid >> 6] = v;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off);
+      incl += lane >= off ? up : 0;
+    }
+    if (lane == 63) sh.wave_sum[tid >> 6] = incl;
     __syncthreads();
-    int offset = 0;
+    int offset = incl - v;
     for (int w = 0; w < (tid >> 6); ++w) offset += sh.wave_sum[w];
-    if (tid < ATTPC_NUM_TB) sh.cum[tid] = v + offset;
+#pragma unroll
+    for (int k = 0; k < BINS_PER_THREAD; ++k) {
+      const int bin = tid * BINS_PER_THREAD + k;
+      if (bin < ATTPC_NUM_TB) sh.cum[bin] = local[k] + offset;
+    }
   }
   __syncthreads();
 
@@ -271,7 +318,9 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
       __syncthreads();
       PHASE_MARK(3);
 
-      // rows -> runs -> this wave's queue -> table, 64 mesh rows per wave at a time
+      // rows -> runs -> this wave's queue -> table, 64 mesh rows per wave at a time.  The row
+      // code is written branch-free (selects, clamped addresses, a dump slot for disabled queue
+      // writes): divergent `if`s cost more exec-mask bookkeeping than the work they skip.
       bool ok = true;
       {
         const int n_rows = sh.n_stage * MESH;
@@ -279,10 +328,10 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
         uint32_t* __restrict__ q_key = sh.queue[wave][0];
         uint32_t* __restrict__ q_chg = sh.queue[wave][1];
         for (int row0 = wave * 64; row0 < n_rows; row0 += SC_THREADS) {  // wave-uniform trip count
-          const int row = row0 + lane;
-          const bool have = row < n_rows;
-          const int st = have ? row / MESH : 0;
-          const int i = have ? row - st * MESH : 0;
+          const int row = min(row0 + lane, n_rows - 1);
+          const bool have = row0 + lane < n_rows;
+          const int st = row / MESH;
+          const int i = row - st * MESH;
           const int tbw = sh.st_tb[st];
           const bool point = (tbw & (1 << 30)) != 0;
           const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
@@ -291,42 +340,59 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
           // point_transport (transporter.py:123-169): all electrons straight down.  With
           // sigma == 0 every mesh line sits on the centre: row 0, pixel 0 stand for the sample.
           const bool live = have && ix >= 0 && (!point || i == 0);
+          const int16_t* __restrict__ lut_row = lut + max(ix, 0) * lut_n;
           int raw[MESH];
-          const int16_t* __restrict__ lut_row = lut + (live ? ix : 0) * lut_n;
 #pragma unroll
-          for (int j = 0; j < MESH; ++j) {  // 10 independent gathers in flight
+          for (int j = 0; j < MESH; ++j) {  // 10 independent gathers in flight (clamped address)
             const int iy = sh.st_iy[st][j];
-            raw[j] = (live && iy >= 0 && (!point || j == 0)) ? (int)lut_row[iy] : -1;
+            const int pad = (int)lut_row[max(iy, 0)];
+            raw[j] = (live && iy >= 0 && (!point || j == 0)) ? pad : -1;
           }
+#ifdef ATTPC_PHASE_TIMERS
+          asm volatile("" ::"v"(raw[0]), "v"(raw[9]));
+          PHASE_SYNC;
+          PHASE_MARK(8);
+#endif
           // truncate per pixel (transporter.py:240-246), merge runs of equal pads: a run's
           // total sits with its last pixel
           double run_q[MESH];
           uint32_t ends = 0;  // bit j: pixel j ends a run on a real pad
+          bool big = false;   // a run does not fit the queue's u32 charge (never for real gains)
           {
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < MESH; ++j) {
               const double w = point ? 1.0 : sh.wtab[i * MESH + j];
-              if (raw[j] >= 0) acc += trunc(w * n_el);
+              const double t = trunc(w * n_el);
+              acc += raw[j] >= 0 ? t : 0.0;
               const bool last = (j == MESH - 1) || (raw[j < MESH - 1 ? j + 1 : j] != raw[j]);
               run_q[j] = acc;
-              if (last) {
-                if (raw[j] >= 0) {
-                  if (acc >= 4294967296.0) {  // does not fit the queue's u32: insert directly (rare)
-                    ok = table_add(sh, word_hi | (uint32_t)raw[j], acc) && ok;
-                  } else {
-                    ends |= 1u << j;
-                  }
-                }
-                acc = 0.0;
+              ends |= (last && raw[j] >= 0) ? (1u << j) : 0u;
+              big = big || (last && acc >= 4294967296.0);
+              acc = last ? 0.0 : acc;
+            }
+          }
+          if (__any(big)) {  // rare: such rows go pixel by pixel straight into the table
+            if (big) {
+              ends = 0;
+#pragma unroll 1
+              for (int j = 0; j < MESH && ok; ++j) {
+                const int iy = sh.st_iy[st][j];
+                const int pad = (live && iy >= 0 && (!point || j == 0)) ? (int)lut_row[max(iy, 0)] : -1;
+                if (pad >= 0) ok = table_add(sh, word_hi | (uint32_t)pad, (unsigned long long)((point ? 1.0 : sh.wtab[i * MESH + j]) * n_el));
               }
             }
           }
+#ifdef ATTPC_PHASE_TIMERS
+          asm volatile("" ::"v"(ends), "v"(run_q[9]));
+          PHASE_SYNC;
+          PHASE_MARK(9);
+#endif
           const int n_runs = __popc(ends);
           int incl = n_runs;  // wave prefix sum -> queue positions
           for (int off = 1; off < 64; off <<= 1) {
             const int up = __shfl_up(incl, off);
-            if (lane >= off) incl += up;
+            incl += lane >= off ? up : 0;
           }
           const int wave_total = __shfl(incl, 63);
           const int first = incl - n_runs;
@@ -334,16 +400,22 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
             int e = first - pass0;  // queue position of this lane's next run in this pass
 #pragma unroll
             for (int j = 0; j < MESH; ++j) {
-              if (ends & (1u << j)) {
-                if (e >= 0 && e < WAVE_QUEUE) {
-                  q_key[e] = word_hi | (uint32_t)raw[j];
-                  q_chg[e] = (uint32_t)run_q[j];
-                }
-                e++;
-              }
+              const bool put = ((ends >> j) & 1u) && e >= 0 && e < WAVE_QUEUE;
+              const int at = put ? e : WAVE_QUEUE;  // WAVE_QUEUE = dump slot
+              q_key[at] = word_hi | (uint32_t)raw[j];
+              q_chg[at] = (uint32_t)run_q[j];
+              e += (int)((ends >> j) & 1u);
             }
             const int n_q = min(wave_total - pass0, WAVE_QUEUE);
-            for (int k = lane; k < n_q && ok; k += 64) ok = table_add(sh, q_key[k], (double)q_chg[k]);
+#ifdef ATTPC_PHASE_TIMERS
+            PHASE_SYNC;
+            PHASE_MARK(10);
+#endif
+            for (int k = lane; k < n_q && ok; k += 64) ok = table_add(sh, q_key[k], (unsigned long long)q_chg[k]);
+#ifdef ATTPC_PHASE_TIMERS
+            PHASE_SYNC;
+            PHASE_MARK(11);
+#endif
           }
           if (__any(!ok)) break;  // table too full: the whole wave stops together (shuffles above)
         }
@@ -414,12 +486,12 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     for (unsigned int r = tid; r < n_rows; r += SC_THREADS) {
       const uint32_t slot = (&sh.queue[0][0][0])[r];
       const uint32_t word = sh.keys[slot];
-      const double q = sh.chg[slot];
+      const unsigned long long q = sh.chg[slot];
       sh.keys[slot] = EMPTY;
-      sh.chg[slot] = 0.0;
+      sh.chg[slot] = 0ull;
       const uint32_t key = word & KEY_MASK;
       const int pad = (int)(key & 0x3fffu), tb = (int)(key >> 14);
-      my_charge += (unsigned long long)q;
+      my_charge += q;
       my_keys += (event << 24) + (unsigned long long)key;
       if (base != ~0ull) {
         const unsigned long long row = base + r;
@@ -428,7 +500,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
         double* o = a.out.points + row * 3;
         o[0] = (double)pad;
         o[1] = (double)tb + ua;
-        o[2] = q;
+        o[2] = (double)q;
         a.out.labels[row] = (int64_t)a.layout.indices[word >> 24];
       }
     }

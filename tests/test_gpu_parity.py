@@ -288,6 +288,25 @@ def test_sim_run_vs_oracle(ctx, orc, name, n):
     assert abs(int(st["charge_checksum"]) - int(ref["stats"][2])) <= 8 * st["n_points"]
 
 
+def test_multichunk_assembly_and_buffer_growth(orc, monkeypatch):
+    """Tiny chunks (host CSR assembly across chunks and windows) and deliberately undersized
+    device buffers (arena / cloud / segment list grow-and-rerun path) give the same clouds."""
+    monkeypatch.setenv("ATTPC_TEST_TINY_BUFFERS", "1")
+    fresh = _abi.Context(0)
+    inp = Inputs("o16aa")
+    eng = _engine(inp, fresh, chunk_events=7)
+    n = 40
+    res = eng.run(n, seed=31, first_event=9, fetch=True, capacity_per_event=64)  # also E_CAPACITY retry
+    ref = orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=31, first=9, n=n, capacity=1 << 21, threads=8)
+    np.testing.assert_array_equal(res["offsets"], ref["offsets"])
+    for e in range(n):
+        lo, hi = ref["offsets"][e], ref["offsets"][e + 1]
+        compare_clouds(*sort_cloud(res["points"][lo:hi], res["labels"][lo:hi]),
+                       *sort_cloud(ref["points"][lo:hi], ref["labels"][lo:hi]))
+    assert res["stats"]["n_failed"] == 0
+    fresh.close()
+
+
 # ---------------------------------------------------------------- size-independent properties
 def test_invariance_chunks_shards_residency(ctx):
     """Same events whatever the chunk size, the split of the id range (what 2/4/8 GPUs do) or

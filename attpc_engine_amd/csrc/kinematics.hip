@@ -210,8 +210,9 @@ __global__ __launch_bounds__(256) void kin_calculate_kernel(attpc_kin_desc d, ui
   const double* ex = ex_in + (size_t)i * d.n_steps;
   const double* th = th_in + (size_t)i * d.n_steps;
   const double* ph = ph_in + (size_t)i * d.n_steps;
-  if (!reaction_allowed(d.masses, e_beam, ex[0])) { status_out[i] = 1; return; }
-  if (below_nr_threshold(d.masses, e_beam, ex[0])) { status_out[i] = -1; return; }
+  const bool allowed0 = reaction_allowed(d.masses, e_beam, ex[0]);          // reaction.py:70-101
+  const bool below_nr = below_nr_threshold(d.masses, e_beam, ex[0]);        // reaction.py:136-143
+  if (!allowed0 || below_nr) { status_out[i] = allowed0 ? -1 : (below_nr ? -2 : 1); return; }
   const P4 target = {0.0, 0.0, 0.0, d.masses[0]};
   const P4 proj = {0.0, 0.0, sqrt(e_beam * (e_beam + 2.0 * d.masses[1])), e_beam + d.masses[1]};
   const P4 parent = {0.0, 0.0, proj.z, target.t + proj.t};

@@ -101,7 +101,7 @@ class Reaction:
     def is_excitation_allowed(self, projectile_energy: float, residual_excitation: float) -> bool:
         """True iff m_ejectile + m_residual + Ex < E_cm (reference reaction.py:70-101)."""
         _, status = device_calculate(self, [], projectile_energy, [residual_excitation], [0.0], [0.0])
-        return bool(status[0] != 1)
+        return bool(status[0] not in (1, -2))
 
     def calculate(
         self,
@@ -114,7 +114,7 @@ class Reaction:
         p4, status = device_calculate(
             self, [], projectile_energy, [residual_excitation], [ejectile_polar], [ejectile_azimuthal]
         )
-        if status[0] == -1:
+        if status[0] in (-1, -2):
             raise ValueError("Beam energy below kinematic threshold!")
         return [FourVector(*row) for row in p4[0]]
 

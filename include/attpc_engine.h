@@ -190,7 +190,9 @@ ATTPC_API int32_t attpc_kin_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_ev
  * (kinematics/reaction.py:70-178) followed by Decay.* (:230-303) per decay.
  * beam_energy [n]; ex, polar, azim [n, n_steps]; p4 [n, n_rows, 4];
  * status [n]: 0 ok, k+1 = step k not energetically allowed (rows from step k on are NaN),
- * -1 = reaction below the non-relativistic threshold (reaction.py:136-143). */
+ * -1 = reaction allowed but below the non-relativistic threshold formula of
+ * Reaction.calculate (reaction.py:136-143, where the reference raises ValueError),
+ * -2 = both not allowed and below that threshold. */
 ATTPC_API int32_t attpc_kin_calculate(attpc_ctx* ctx, uint64_t n, const double* beam_energy,
                             const double* ex, const double* polar, const double* azim,
                             double* p4, int32_t* status);

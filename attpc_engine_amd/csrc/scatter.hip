@@ -77,7 +77,11 @@ constexpr int WAVE_QUEUE = 256;             // queued runs per wave and pass (ty
 constexpr int N_WAVES = SC_THREADS / 64;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;
-constexpr int WINDOW_BUDGET = HASH_CAP / 28; // samples per window to start with (~14 keys/sample, half full)
+constexpr int TARGET_KEYS = HASH_CAP / 2;          // aimed-at table fill: insert cost rises steeply beyond ~55 %
+// Estimated distinct keys a sample adds: the mesh is 6 sigma_t wide and sigma_t^2 grows linearly with
+// the time bucket, so the pad count grows ~linearly: 2 + tb/20 (3 at the micromegas, 27 at tb 511;
+// the measured mean for the headline workload is 14.6).  Windows are cut on this estimate.
+__device__ __forceinline__ int key_estimate(int tb) { return 2 + tb / 20; }
 constexpr int MESH = ATTPC_MESH_STEPS;
 constexpr int PIXELS = MESH * MESH;
 constexpr int BINS_PER_THREAD = (ATTPC_NUM_TB + SC_THREADS - 1) / SC_THREADS;
@@ -96,7 +100,7 @@ struct __align__(16) ScatterShared {
   int st_tb[STAGE];           // bits 0..9 time bucket, 24..26 position in `indices`, 30 point transport
   int blocks[ATTPC_MAX_SIM][MAX_BLOCKS_PER_TRACK];  // arena block ids of the event's tracks
   int cnt[ATTPC_MAX_SIM + 1]; // exclusive prefix of kept samples per simulated nucleus
-  int cum[ATTPC_NUM_TB];      // inclusive prefix sum of kept samples per time bucket
+  int cum[ATTPC_NUM_TB];      // inclusive prefix sum of estimated keys per time bucket
   int wave_sum[SC_THREADS / 64];
   int win_a, win_b, win_samples, budget, n_stage, overflow, done, failed, retried;
   unsigned int wg_cursor;
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
       acc += a.trk.counts[track0 + k];
     }
     for (int k = n_sim; k <= ATTPC_MAX_SIM; ++k) sh.cnt[k] = acc;
-    sh.win_a = 0; sh.win_b = 0; sh.budget = WINDOW_BUDGET; sh.overflow = 0; sh.done = 0;
+    sh.win_a = 0; sh.win_b = 0; sh.budget = TARGET_KEYS; sh.overflow = 0; sh.done = 0;
     sh.failed = 0; sh.retried = 0; sh.charge_sum = 0ull; sh.key_sum = 0ull;
   }
   clear_table(sh);
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
     // t < 0 (sigma_t would be NaN: undefined in the reference) and tb >= 512 (removed by the
     // 0 <= tb < 512 mask of simulator.py:111-113) never reach the output
-    if (t >= 0.0 && t < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)t], 1);
+    if (t >= 0.0 && t < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)t], key_estimate((int)t));
   }
   __syncthreads();
   {  // inclusive prefix sum over the 512 buckets: per-thread serial part, wave scan, wave offsets
@@ -411,7 +415,15 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
             PHASE_SYNC;
             PHASE_MARK(10);
 #endif
+#if defined(ATTPC_ABL_NODRAIN)
+            for (int k = lane; k < n_q && ok; k += 64) { asm volatile("" ::"v"(q_key[k]), "v"(q_chg[k])); }
+#elif defined(ATTPC_ABL_DOUBLE)
+            for (int k = lane; k < n_q && ok; k += 64) { ok = table_add(sh, q_key[k], (unsigned long long)q_chg[k]); ok = table_add(sh, q_key[k], 0ull) && ok; }
+#elif defined(ATTPC_ABL_PERMUTE)
+            for (int k0 = lane; k0 < WAVE_QUEUE && ok; k0 += 64) { const int k = (k0 * 37) & (WAVE_QUEUE - 1); if (k < n_q) ok = table_add(sh, q_key[k], (unsigned long long)q_chg[k]); }
+#else
             for (int k = lane; k < n_q && ok; k += 64) ok = table_add(sh, q_key[k], (unsigned long long)q_chg[k]);
+#endif
 #ifdef ATTPC_PHASE_TIMERS
             PHASE_SYNC;
             PHASE_MARK(11);
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
           sh.failed = 1;          // one time bucket alone exceeds the table: not representable
           sh.overflow = 0;
           sh.win_b = win_a + 1;   // skip this bucket
-          sh.budget = WINDOW_BUDGET;
+          sh.budget = TARGET_KEYS;
         } else {
           sh.budget = sh.win_samples / 2 > 0 ? sh.win_samples / 2 : 1;
         }
@@ -475,10 +487,10 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
         }
       }
       sh.base = base;
-      // adapt: aim at half-full tables (keys per sample varies with track geometry)
-      const int per_sample_x16 = sh.win_samples > 0 ? (int)(n_rows * 16u) / sh.win_samples : 0;
-      sh.budget = per_sample_x16 > 0 ? (HASH_CAP / 2) * 16 / per_sample_x16 : WINDOW_BUDGET;
-      if (sh.budget < 32) sh.budget = 32;
+      // adapt the estimate to this event: observed keys per estimated key of the last window
+      const int ratio_x16 = sh.win_samples > 0 ? (int)(n_rows * 16u) / sh.win_samples : 16;
+      sh.budget = ratio_x16 > 0 ? TARGET_KEYS * 16 / ratio_x16 : TARGET_KEYS;
+      sh.budget = min(max(sh.budget, TARGET_KEYS / 8), TARGET_KEYS * 4);
     }
     __syncthreads();
     PHASE_MARK(6);

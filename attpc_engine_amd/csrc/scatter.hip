@@ -78,10 +78,16 @@ constexpr int N_WAVES = SC_THREADS / 64;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;
 constexpr int TARGET_KEYS = HASH_CAP / 2;          // aimed-at table fill: insert cost rises steeply beyond ~55 %
-// Estimated distinct keys a sample adds: the mesh is 6 sigma_t wide and sigma_t^2 grows linearly with
-// the time bucket, so the pad count grows ~linearly: 2 + tb/20 (3 at the micromegas, 27 at tb 511;
-// the measured mean for the headline workload is 14.6).  Windows are cut on this estimate.
-__device__ __forceinline__ int key_estimate(int tb) { return 2 + tb / 20; }
+// Estimated distinct keys a sample adds: its mesh is 6 sigma_t wide, pads have a ~4.9 mm pitch,
+// so it touches about (1 + 6 sigma_t / 4.9 mm)^2 pads; sigma_t^2 = 2 D dv tb / E.  `spread` =
+// (6 / 4.9 mm)^2 * 2 D dv / E is a per-configuration constant.  (Default detector: 3 keys at the
+// micromegas, 15 at tb 256, 28 at tb 511; the measured mean of the headline workload is 14.6.)
+// Windows are cut on the prefix sum of this estimate; the ratio observed/estimated of each
+// flushed window rescales the next one.
+__device__ __forceinline__ int key_estimate(int tb, float spread) {
+  const float r = 1.0f + sqrtf(spread * (float)tb);
+  return (int)fminf(r * r + 0.5f, 100.0f);  // a sample has 100 pixels
+}
 constexpr int MESH = ATTPC_MESH_STEPS;
 constexpr int PIXELS = MESH * MESH;
 constexpr int BINS_PER_THREAD = (ATTPC_NUM_TB + SC_THREADS - 1) / SC_THREADS;
@@ -194,6 +200,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
   const int lut_n = a.det.lut_n, lut_lo = a.det.lut_lo;
   const int16_t* __restrict__ lut = a.det.pad_lut;
   const double* __restrict__ arena = a.trk.arena;
+  const float spread = (float)((6.0 / 4.9e-3) * (6.0 / 4.9e-3) * 2.0 * a.det.diffusion * a.det.dv / a.det.efield);
 
   PHASE_DECL;
   // ---- init ----
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
     // t < 0 (sigma_t would be NaN: undefined in the reference) and tb >= 512 (removed by the
     // 0 <= tb < 512 mask of simulator.py:111-113) never reach the output
-    if (t >= 0.0 && t < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)t], key_estimate((int)t));
+    if (t >= 0.0 && t < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)t], key_estimate((int)t, spread));
   }
   __syncthreads();
   {  // inclusive prefix sum over the 512 buckets: per-thread serial part, wave scan, wave offsets
@@ -415,15 +422,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
             PHASE_SYNC;
             PHASE_MARK(10);
 #endif
-#if defined(ATTPC_ABL_NODRAIN)
-            for (int k = lane; k < n_q && ok; k += 64) { asm volatile("" ::"v"(q_key[k]), "v"(q_chg[k])); }
-#elif defined(ATTPC_ABL_DOUBLE)
-            for (int k = lane; k < n_q && ok; k += 64) { ok = table_add(sh, q_key[k], (unsigned long long)q_chg[k]); ok = table_add(sh, q_key[k], 0ull) && ok; }
-#elif defined(ATTPC_ABL_PERMUTE)
-            for (int k0 = lane; k0 < WAVE_QUEUE && ok; k0 += 64) { const int k = (k0 * 37) & (WAVE_QUEUE - 1); if (k < n_q) ok = table_add(sh, q_key[k], (unsigned long long)q_chg[k]); }
-#else
             for (int k = lane; k < n_q && ok; k += 64) ok = table_add(sh, q_key[k], (unsigned long long)q_chg[k]);
-#endif
 #ifdef ATTPC_PHASE_TIMERS
             PHASE_SYNC;
             PHASE_MARK(11);

@@ -163,7 +163,7 @@ def measured_traffic(workload: str, kernel: str, events_per_launch: float):
 
 
 def cpu_baseline(workload: str, seed: int) -> dict:
-    """The CPU oracle on this host's cores, bounded sample (~10-30 s), same workload/seeds."""
+    """The CPU oracle on this host's cores, bounded sample (~20 s), same workload/seeds."""
     from oracle import pyoracle as orc
     from tests.helpers import Inputs
 
@@ -173,7 +173,7 @@ def cpu_baseline(workload: str, seed: int) -> dict:
     t0 = time.perf_counter()
     orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=seed, first=0, n=probe, threads=cores)
     rate = probe / (time.perf_counter() - t0)
-    n = int(min(max(probe, rate * 15.0), 200_000))
+    n = int(min(max(probe, rate * 20.0), 200_000))
     t0 = time.perf_counter()
     orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=seed, first=0, n=n, threads=cores)
     dt = time.perf_counter() - t0

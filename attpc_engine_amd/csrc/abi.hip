@@ -46,7 +46,7 @@ struct attpc_ctx {
   // chunk buffers
   DevBuf p4, vertex, status, attempts;
   DevBuf arena, block_table, counts, n_steps, trk_ctrl;
-  DevBuf points, labels, segments, out_ctrl;
+  DevBuf points, labels, segments, out_ctrl, asm_labels;
   DevBuf scratch[8];
   size_t arena_blocks = 0;
   int64_t cloud_capacity = 0, seg_capacity = 0;
@@ -235,6 +235,25 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
   return fail(ctx, ATTPC_E_HIP, "detector chunk did not fit after repeated buffer growth");
 }
 
+// Device-side CSR assembly: segment s (one flushed window of one event) is copied to row
+// dst[s] of the event-ordered arrays, so the host receives one contiguous block per chunk.
+__global__ __launch_bounds__(256) void gather_segments_kernel(const Segment* __restrict__ segs,
+                                                              const int64_t* __restrict__ dst, uint32_t n_segs,
+                                                              const double* __restrict__ points,
+                                                              const int64_t* __restrict__ labels,
+                                                              double* __restrict__ out_points,
+                                                              int64_t* __restrict__ out_labels) {
+  for (uint32_t s = blockIdx.x; s < n_segs; s += gridDim.x) {
+    const Segment sg = segs[s];
+    const double* src_p = points + sg.offset * 3;
+    double* dst_p = out_points + dst[s] * 3;
+    for (int i = threadIdx.x; i < sg.count * 3; i += 256) dst_p[i] = src_p[i];
+    const int64_t* src_l = labels + sg.offset;
+    int64_t* dst_l = out_labels + dst[s];
+    for (int i = threadIdx.x; i < sg.count; i += 256) dst_l[i] = src_l[i];
+  }
+}
+
 // copy one chunk's cloud to the caller's CSR arrays (events in order)
 int32_t assemble_chunk(attpc_ctx* ctx, const ChunkResult& r, uint32_t n, uint64_t chunk_first_local,
                        attpc_cloud_out* out, int64_t* row_cursor, bool* over_capacity) {
@@ -253,17 +272,28 @@ int32_t assemble_chunk(attpc_ctx* ctx, const ChunkResult& r, uint32_t n, uint64_
     return ATTPC_OK;
   }
   if (r.rows == 0) return ATTPC_OK;
-  std::vector<double> pts((size_t)r.rows * 3);
-  std::vector<int64_t> lab((size_t)r.rows);
-  HIP_TRY(ctx, hipMemcpy(pts.data(), ctx->points.p, pts.size() * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(lab.data(), ctx->labels.p, lab.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+  std::vector<int64_t> dst(r.segs);
   std::vector<int64_t> fill(start.begin(), start.end() - 1);
-  for (const Segment& s : segs) {  // segments of one event appear in window order
-    const int64_t dst = base + fill[s.event];
-    std::memcpy(out->points + dst * 3, pts.data() + s.offset * 3, (size_t)s.count * 3 * sizeof(double));
-    std::memcpy(out->labels + dst, lab.data() + s.offset, (size_t)s.count * sizeof(int64_t));
-    fill[s.event] += s.count;
+  for (size_t s = 0; s < segs.size(); ++s) {  // segments of one event appear in window order
+    dst[s] = fill[segs[s].event];
+    fill[segs[s].event] += segs[s].count;
   }
+  int32_t rc;
+  if ((rc = ensure(ctx, ctx->scratch[6], r.segs * sizeof(int64_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch[7], (size_t)r.rows * 3 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->asm_labels, (size_t)r.rows * sizeof(int64_t)))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[6].p, dst.data(), r.segs * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)std::min<uint64_t>(r.segs, 65535)), dim3(256), 0,
+                     ctx->stream, static_cast<const Segment*>(ctx->segments.p),
+                     static_cast<const int64_t*>(ctx->scratch[6].p), (uint32_t)r.segs,
+                     static_cast<const double*>(ctx->points.p), static_cast<const int64_t*>(ctx->labels.p),
+                     static_cast<double*>(ctx->scratch[7].p), static_cast<int64_t*>(ctx->asm_labels.p));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out->points + base * 3, ctx->scratch[7].p, (size_t)r.rows * 3 * sizeof(double),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out->labels + base, ctx->asm_labels.p, (size_t)r.rows * sizeof(int64_t),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return ATTPC_OK;
 }
 
@@ -317,7 +347,7 @@ int32_t attpc_ctx_destroy(attpc_ctx* ctx) {
   free_all(ctx->det_allocs);
   DevBuf* bufs[] = {&ctx->p4, &ctx->vertex, &ctx->status, &ctx->attempts, &ctx->arena, &ctx->block_table,
                     &ctx->counts, &ctx->n_steps, &ctx->trk_ctrl, &ctx->points, &ctx->labels, &ctx->segments,
-                    &ctx->out_ctrl};
+                    &ctx->out_ctrl, &ctx->asm_labels};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& b : ctx->scratch)

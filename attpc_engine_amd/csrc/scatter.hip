@@ -109,7 +109,7 @@ struct __align__(16) ScatterShared {
   int cum[ATTPC_NUM_TB];      // inclusive prefix sum of estimated keys per time bucket
   int wave_sum[SC_THREADS / 64];
   int win_a, win_b, win_samples, budget, n_stage, overflow, done, failed, retried;
-  unsigned int wg_cursor;
+  unsigned int wg_cursor, n_keys;
   unsigned long long base;
   unsigned long long charge_sum, key_sum;
 };
@@ -177,6 +177,7 @@ __device__ __forceinline__ bool table_add(ScatterShared& sh, uint32_t want, unsi
       if (old == EMPTY || (old & KEY_MASK) == key) {
         h = b * BUCKET + pos;
         cur = old == EMPTY ? want : old;
+        if (old == EMPTY) atomicAdd(&sh.n_keys, 1u);  // rows of the window's flush
         break;
       }
       continue;  // lost the slot to another key: look at the bucket again
@@ -187,6 +188,22 @@ __device__ __forceinline__ bool table_add(ScatterShared& sh, uint32_t want, unsi
   if (cur < want) atomicMax(&sh.keys[h], want);
   atomicAdd(&sh.chg[h], q);
   return true;
+}
+
+// Next window [win_a, win_b) of time buckets: starts at the first non-empty bucket >= `from` and
+// extends while the estimated key count stays within the budget (at least one bucket).  Thread 0.
+__device__ __forceinline__ void select_window(ScatterShared& sh, int from) {
+  const int before = from > 0 ? sh.cum[from - 1] : 0;
+  const int a0 = upper_bound(sh.cum, from, ATTPC_NUM_TB, before);
+  if (a0 >= ATTPC_NUM_TB) {
+    sh.done = 1;
+    return;
+  }
+  int b0 = upper_bound(sh.cum, a0, ATTPC_NUM_TB, before + sh.budget);
+  if (b0 <= a0) b0 = a0 + 1;
+  sh.win_a = a0;
+  sh.win_b = b0;
+  sh.win_samples = sh.cum[b0 - 1] - before;
 }
 
 __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
@@ -217,7 +234,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     }
     for (int k = n_sim; k <= ATTPC_MAX_SIM; ++k) sh.cnt[k] = acc;
     sh.win_a = 0; sh.win_b = 0; sh.budget = TARGET_KEYS; sh.overflow = 0; sh.done = 0;
-    sh.failed = 0; sh.retried = 0; sh.charge_sum = 0ull; sh.key_sum = 0ull;
+    sh.failed = 0; sh.retried = 0; sh.charge_sum = 0ull; sh.key_sum = 0ull; sh.n_keys = 0u;
   }
   clear_table(sh);
   __syncthreads();
@@ -265,27 +282,13 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
   }
   __syncthreads();
 
+  if (tid == 0) select_window(sh, 0);
+  __syncthreads();
   unsigned long long my_charge = 0ull, my_keys = 0ull;
   PHASE_MARK(1);
 
   for (;;) {
-    // ---- choose the next window [win_a, win_b) of time buckets ----
-    if (tid == 0) {
-      const int from = sh.overflow ? sh.win_a : sh.win_b;  // overflow: same start, smaller budget
-      sh.overflow = 0;
-      const int before = from > 0 ? sh.cum[from - 1] : 0;
-      const int a0 = upper_bound(sh.cum, from, ATTPC_NUM_TB, before);
-      if (a0 >= ATTPC_NUM_TB) {
-        sh.done = 1;
-      } else {
-        int b0 = upper_bound(sh.cum, a0, ATTPC_NUM_TB, before + sh.budget);
-        if (b0 <= a0) b0 = a0 + 1;
-        sh.win_a = a0;
-        sh.win_b = b0;
-        sh.win_samples = sh.cum[b0 - 1] - before;
-      }
-    }
-    __syncthreads();
+    // the window was chosen by thread 0 before the barrier that ended the previous iteration
     if (sh.done) break;
     const int win_a = sh.win_a, win_b = sh.win_b;
     PHASE_MARK(2);
@@ -450,31 +453,55 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
         } else {
           sh.budget = sh.win_samples / 2 > 0 ? sh.win_samples / 2 : 1;
         }
+        const int from = sh.overflow ? sh.win_a : sh.win_b;  // overflow: same start, smaller budget
+        sh.overflow = 0;
+        sh.n_keys = 0u;
+        select_window(sh, from);
       }
       __syncthreads();
       continue;
     }
 
-    // ---- flush: compact the occupied slots, reserve one contiguous range, write rows ----
-    if (tid == 0) sh.wg_cursor = 0u;
-    __syncthreads();
-    for (int i0 = 0; i0 < HASH_CAP; i0 += SC_THREADS) {
-      const int i = i0 + tid;
-      const bool occ = sh.keys[i] != EMPTY;
-      const unsigned long long m = __ballot(occ);
-      unsigned int wbase = 0;
-      if (lane == 0 && m) wbase = atomicAdd(&sh.wg_cursor, (unsigned int)__popcll(m));
-      wbase = __shfl(wbase, 0);
-      if (occ) (&sh.queue[0][0][0])[wbase + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    // ---- flush: reserve one contiguous range of rows, compact the occupied slots, write rows ----
+    // (the last barrier of the rows phase made every claim visible: n_keys is final)
+    const unsigned int n_rows = sh.n_keys;
+    unsigned long long g_base = 0ull, g_seg = 0ull;
+    if (tid == 0) {
+      sh.wg_cursor = 0u;
+      if (n_rows) {  // two independent global atomics in flight while the slots are compacted
+        g_base = atomicAdd(&a.out.ctrl[0], (unsigned long long)n_rows);
+        g_seg = atomicAdd(&a.out.ctrl[1], 1ull);
+      }
     }
     __syncthreads();
-    const unsigned int n_rows = sh.wg_cursor;
+    {  // every wave compacts its own contiguous slice of the table with a single LDS atomic
+      constexpr int PER_WAVE = HASH_CAP / N_WAVES;
+      constexpr int ITERS = PER_WAVE / 64;
+      const int wave = tid >> 6;
+      unsigned long long occ_mask[ITERS];
+      unsigned int cnt = 0;
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        occ_mask[it] = __ballot(sh.keys[wave * PER_WAVE + it * 64 + lane] != EMPTY);
+        cnt += (unsigned int)__popcll(occ_mask[it]);
+      }
+      unsigned int wbase = 0;
+      if (lane == 0 && cnt) wbase = atomicAdd(&sh.wg_cursor, cnt);
+      wbase = __shfl(wbase, 0);
+      uint32_t* __restrict__ list = &sh.queue[0][0][0];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const unsigned long long m = occ_mask[it];
+        if ((m >> lane) & 1ull)
+          list[wbase + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(wave * PER_WAVE + it * 64 + lane);
+        wbase += (unsigned int)__popcll(m);
+      }
+    }
     if (tid == 0) {
       unsigned long long base = 0ull;
       if (n_rows) {
-        base = atomicAdd(&a.out.ctrl[0], (unsigned long long)n_rows);
-        const unsigned long long si = atomicAdd(&a.out.ctrl[1], 1ull);
-        if (base + n_rows > (unsigned long long)a.out.capacity || si >= (unsigned long long)a.out.seg_capacity) {
+        base = g_base;
+        if (base + n_rows > (unsigned long long)a.out.capacity || g_seg >= (unsigned long long)a.out.seg_capacity) {
           a.out.ctrl[6] = 1ull;  // out of capacity: host re-runs the chunk with larger buffers
           base = ~0ull;
         } else {
@@ -482,14 +509,16 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
           sg.event = (int32_t)e_local;
           sg.count = (int32_t)n_rows;
           sg.offset = (int64_t)base;
-          a.out.segments[si] = sg;
+          a.out.segments[g_seg] = sg;
         }
       }
       sh.base = base;
+      sh.n_keys = 0u;
       // adapt the estimate to this event: observed keys per estimated key of the last window
       const int ratio_x16 = sh.win_samples > 0 ? (int)(n_rows * 16u) / sh.win_samples : 16;
       sh.budget = ratio_x16 > 0 ? TARGET_KEYS * 16 / ratio_x16 : TARGET_KEYS;
       sh.budget = min(max(sh.budget, TARGET_KEYS / 8), TARGET_KEYS * 4);
+      select_window(sh, win_b);  // the next window, published by the barrier after the row stores
     }
     __syncthreads();
     PHASE_MARK(6);

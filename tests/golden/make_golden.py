@@ -354,6 +354,26 @@ def main() -> None:
         if (z, a) not in species:
             species.append((z, a))
         print(f"track {i}: Z={z} A={a} KE={ke} rows={len(track)} electrons={int(electrons.sum())}")
+    # ---- G6b the same initial conditions integrated TIGHTLY (DOP853, rtol 1e-12) through the
+    # reference's own equation_of_motion and terminal events: the converged solution that both the
+    # reference's Radau (rtol 1e-3) and the engine's fixed-grid RK4 approximate ----
+    from scipy.integrate import solve_ivp
+    for i, (z, a, ke, pol, azi, vtx) in enumerate(cases):
+        nuc = nmap.get_data(z, a)
+        mom = tk[f"mom{i}"]
+        y0 = np.zeros(6)
+        y0[:3] = vtx
+        y0[3:] = mom[:3] / nuc.mass
+        events = [solver.stop_condition, solver.forward_z_bound_condition, solver.backward_z_bound_condition,
+                  solver.rho_bound_condition]  # terminal/direction attributes were set by generate_trajectory
+        sol = solve_ivp(solver.equation_of_motion, (0.0, 1.0), y0, method="DOP853", events=events,
+                        t_eval=solver.TIME_STEPS, rtol=1e-12, atol=1e-14, max_step=2e-9,
+                        args=(det.bfield * -1.0, det.efield * -1.0, gas, nuc))
+        tight = sol.y.T
+        tk[f"tight_nrows{i}"] = len(tight)
+        tk[f"tight{i}"] = tight[::10].copy()
+        tk[f"tight_last{i}"] = tight[-1].copy()
+        print(f"tight track {i}: rows={len(tight)} (Radau rows={int(tk[f'nrows{i}'])})")
     tk["species"] = np.array(species)
     tk["dedx_tables"] = np.stack([gas.tables[s] for s in species])
     tk["dedx_energies"] = dedx_node_energies()

@@ -308,6 +308,23 @@ def test_multichunk_assembly_and_buffer_growth(orc, monkeypatch):
     fresh.close()
 
 
+@pytest.mark.parametrize("name,n", [("o16aa", 4000), ("be10dp", 4000)])
+def test_bulk_checksums_vs_oracle(ctx, orc, name, n):
+    """A few thousand events, statistics only: the number of cloud points, of kept track samples
+    and the checksum over every (event, time bucket, pad) key equal the oracle's exactly; the
+    charge checksums agree to within the per-point tolerance."""
+    inp = Inputs(name)
+    eng = _engine(inp, ctx)
+    st = eng.run(n, seed=2024, first_event=100)["stats"]
+    ref = orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=2024, first=100, n=n, threads=32)["stats"]
+    assert st["n_points"] == ref[0] and st["n_track_samples"] == ref[1]
+    assert st["key_checksum"] == ref[3] % (1 << 64)
+    diff = (int(st["charge_checksum"]) - int(ref[2] % (1 << 64)) + (1 << 63)) % (1 << 64) - (1 << 63)
+    assert abs(diff) <= 8 * st["n_points"], diff
+    assert st["n_failed"] == 0
+    print(name, "points", st["n_points"], "charge checksum difference (electrons)", diff)
+
+
 # ---------------------------------------------------------------- size-independent properties
 def test_invariance_chunks_shards_residency(ctx):
     """Same events whatever the chunk size, the split of the id range (what 2/4/8 GPUs do) or

@@ -95,6 +95,15 @@ class CloudOut(C.Structure):
     ]
 
 
+class SpyralDesc(C.Structure):
+    _fields_ = [
+        ("response", _dp), ("pad_centers", _dp), ("pad_sizes", _dp),
+        ("n_pads", C.c_int32), ("windows_edge", C.c_int32), ("micromegas_edge", C.c_int32),
+        ("reserved", C.c_int32),
+        ("length", C.c_double), ("adc_threshold", C.c_double),
+    ]
+
+
 class RunStats(C.Structure):
     _fields_ = [
         ("n_events", C.c_uint64), ("n_points", C.c_uint64), ("n_track_samples", C.c_uint64),
@@ -139,7 +148,7 @@ EXPORTED_SYMBOLS = (
     "attpc_version", "attpc_device_count", "attpc_ctx_create", "attpc_ctx_destroy",
     "attpc_last_error", "attpc_set_chunk_events", "attpc_sync", "attpc_kin_configure",
     "attpc_kin_run", "attpc_kin_calculate", "attpc_decay_calculate", "attpc_det_configure", "attpc_det_run",
-    "attpc_sim_run", "attpc_det_tracks", "attpc_spyral_rows",
+    "attpc_sim_run", "attpc_det_tracks", "attpc_spyral_rows", "attpc_spyral_configure", "attpc_sim_run_spyral",
 )
 
 _lib = None
@@ -187,6 +196,8 @@ def load_library() -> C.CDLL:
         ctxp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(EventLayout), _dp, _dp,
         C.POINTER(C.c_int32), C.POINTER(CloudOut), C.POINTER(RunStats),
     ]
+    lib.attpc_sim_run_spyral.argtypes = lib.attpc_sim_run.argtypes
+    lib.attpc_spyral_configure.argtypes = [ctxp, C.POINTER(SpyralDesc)]
     lib.attpc_det_tracks.argtypes = [
         ctxp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(EventLayout), _dp, _dp, C.c_int64,
         _dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

@@ -47,6 +47,11 @@ struct attpc_ctx {
   DevBuf p4, vertex, status, attempts;
   DevBuf arena, block_table, counts, n_steps, trk_ctrl;
   DevBuf points, labels, segments, out_ctrl, asm_labels;
+
+  bool spyral_ready = false;
+  SpyralDev spyral{};
+  std::vector<void*> spyral_allocs;
+  DevBuf sp_rows, sp_labels, sp_event_start, sp_kept, sp_kept_start;
   DevBuf scratch[8];
   size_t arena_blocks = 0;
   int64_t cloud_capacity = 0, seg_capacity = 0;
@@ -254,26 +259,18 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const Segment* __r
   }
 }
 
-// copy one chunk's cloud to the caller's CSR arrays (events in order)
-int32_t assemble_chunk(attpc_ctx* ctx, const ChunkResult& r, uint32_t n, uint64_t chunk_first_local,
-                       attpc_cloud_out* out, int64_t* row_cursor, bool* over_capacity) {
+// Event-ordered (CSR) copy of one chunk's cloud on the device: scratch[7] = points, asm_labels =
+// labels; `start` receives the chunk-local row offset of every event (n + 1 entries).
+int32_t gather_chunk_csr(attpc_ctx* ctx, const ChunkResult& r, uint32_t n, std::vector<int64_t>* start, bool run_gather) {
   std::vector<Segment> segs(r.segs);
   if (r.segs) HIP_TRY(ctx, hipMemcpy(segs.data(), ctx->segments.p, r.segs * sizeof(Segment), hipMemcpyDeviceToHost));
   std::vector<int64_t> counts(n, 0);
   for (const Segment& s : segs) counts[s.event] += s.count;
-  std::vector<int64_t> start(n + 1, 0);
-  for (uint32_t i = 0; i < n; ++i) start[i + 1] = start[i] + counts[i];
-  const int64_t base = *row_cursor;
-  if (out->offsets)
-    for (uint32_t i = 0; i <= n; ++i) out->offsets[chunk_first_local + i] = base + start[i];
-  *row_cursor = base + start[n];
-  if (*row_cursor > out->capacity || !out->points || !out->labels) {
-    if (*row_cursor > out->capacity) *over_capacity = true;
-    return ATTPC_OK;
-  }
-  if (r.rows == 0) return ATTPC_OK;
+  start->assign(n + 1, 0);
+  for (uint32_t i = 0; i < n; ++i) (*start)[i + 1] = (*start)[i] + counts[i];
+  if (!run_gather || r.rows == 0) return ATTPC_OK;
   std::vector<int64_t> dst(r.segs);
-  std::vector<int64_t> fill(start.begin(), start.end() - 1);
+  std::vector<int64_t> fill(start->begin(), start->end() - 1);
   for (size_t s = 0; s < segs.size(); ++s) {  // segments of one event appear in window order
     dst[s] = fill[segs[s].event];
     fill[segs[s].event] += segs[s].count;
@@ -289,10 +286,74 @@ int32_t assemble_chunk(attpc_ctx* ctx, const ChunkResult& r, uint32_t n, uint64_
                      static_cast<const double*>(ctx->points.p), static_cast<const int64_t*>(ctx->labels.p),
                      static_cast<double*>(ctx->scratch[7].p), static_cast<int64_t*>(ctx->asm_labels.p));
   HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // dst is a local vector
+  return ATTPC_OK;
+}
+
+// copy one chunk's cloud to the caller's CSR arrays (events in order)
+int32_t assemble_chunk(attpc_ctx* ctx, const ChunkResult& r, uint32_t n, uint64_t chunk_first_local,
+                       attpc_cloud_out* out, int64_t* row_cursor, bool* over_capacity) {
+  const int64_t base = *row_cursor;
+  const bool fits = out->points && out->labels && base + (int64_t)r.rows <= out->capacity;
+  std::vector<int64_t> start;
+  int32_t rc = gather_chunk_csr(ctx, r, n, &start, fits);
+  if (rc) return rc;
+  if (out->offsets)
+    for (uint32_t i = 0; i <= n; ++i) out->offsets[chunk_first_local + i] = base + start[i];
+  *row_cursor = base + start[n];
+  if (!fits) {
+    if (*row_cursor > out->capacity) *over_capacity = true;
+    return ATTPC_OK;
+  }
+  if (r.rows == 0) return ATTPC_OK;
   HIP_TRY(ctx, hipMemcpyAsync(out->points + base * 3, ctx->scratch[7].p, (size_t)r.rows * 3 * sizeof(double),
                               hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(out->labels + base, ctx->asm_labels.p, (size_t)r.rows * sizeof(int64_t),
                               hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return ATTPC_OK;
+}
+
+// response + threshold + Spyral rows of one chunk on the device, then D2H (rows of 8 doubles)
+int32_t assemble_chunk_spyral(attpc_ctx* ctx, const ChunkResult& r, uint32_t n, uint64_t chunk_first_local,
+                              attpc_cloud_out* out, int64_t* row_cursor, bool* over_capacity) {
+  std::vector<int64_t> start;
+  int32_t rc = gather_chunk_csr(ctx, r, n, &start, true);
+  if (rc) return rc;
+  const int64_t base = *row_cursor;
+  std::vector<int64_t> kept_start(n + 1, 0);
+  if (r.rows) {
+    if ((rc = ensure(ctx, ctx->sp_event_start, (n + 1) * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sp_kept_start, (n + 1) * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sp_kept, n * sizeof(int32_t)))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_event_start.p, start.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    launch_spyral_count(ctx->stream, ctx->spyral, n, static_cast<const int64_t*>(ctx->sp_event_start.p),
+                        static_cast<const double*>(ctx->scratch[7].p), static_cast<int32_t*>(ctx->sp_kept.p));
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<int32_t> kept(n);
+    HIP_TRY(ctx, hipMemcpyAsync(kept.data(), ctx->sp_kept.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < n; ++i) kept_start[i + 1] = kept_start[i] + kept[i];
+  }
+  const int64_t n_kept = kept_start[n];
+  if (out->offsets)
+    for (uint32_t i = 0; i <= n; ++i) out->offsets[chunk_first_local + i] = base + kept_start[i];
+  *row_cursor = base + n_kept;
+  if (*row_cursor > out->capacity || !out->points || !out->labels) {
+    if (*row_cursor > out->capacity) *over_capacity = true;
+    return ATTPC_OK;
+  }
+  if (n_kept == 0) return ATTPC_OK;
+  if ((rc = ensure(ctx, ctx->sp_rows, (size_t)n_kept * 8 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->sp_labels, (size_t)n_kept * sizeof(int64_t)))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_kept_start.p, kept_start.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  launch_spyral_write(ctx->stream, ctx->spyral, n, static_cast<const int64_t*>(ctx->sp_event_start.p),
+                      static_cast<const int64_t*>(ctx->sp_kept_start.p), static_cast<const double*>(ctx->scratch[7].p),
+                      static_cast<const int64_t*>(ctx->asm_labels.p), static_cast<double*>(ctx->sp_rows.p),
+                      static_cast<int64_t*>(ctx->sp_labels.p));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out->points + base * 8, ctx->sp_rows.p, (size_t)n_kept * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out->labels + base, ctx->sp_labels.p, (size_t)n_kept * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return ATTPC_OK;
 }
@@ -345,9 +406,11 @@ int32_t attpc_ctx_destroy(attpc_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   free_all(ctx->kin_allocs);
   free_all(ctx->det_allocs);
+  free_all(ctx->spyral_allocs);
   DevBuf* bufs[] = {&ctx->p4, &ctx->vertex, &ctx->status, &ctx->attempts, &ctx->arena, &ctx->block_table,
                     &ctx->counts, &ctx->n_steps, &ctx->trk_ctrl, &ctx->points, &ctx->labels, &ctx->segments,
-                    &ctx->out_ctrl, &ctx->asm_labels};
+                    &ctx->out_ctrl, &ctx->asm_labels, &ctx->sp_rows, &ctx->sp_labels,
+                    &ctx->sp_event_start, &ctx->sp_kept, &ctx->sp_kept_start};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& b : ctx->scratch)
@@ -577,10 +640,11 @@ int32_t attpc_det_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint6
   return ATTPC_OK;
 }
 
-int32_t attpc_sim_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
-                      const attpc_event_layout* layout, double* p4, double* vertex, int32_t* kin_status,
-                      attpc_cloud_out* out, attpc_run_stats* stats) {
+static int32_t sim_run_impl(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                            const attpc_event_layout* layout, double* p4, double* vertex, int32_t* kin_status,
+                            attpc_cloud_out* out, attpc_run_stats* stats, bool spyral) {
   if (!ctx) return ATTPC_E_INVALID;
+  if (spyral && !ctx->spyral_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_spyral_configure has not been called");
   if (!ctx->kin_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_kin_configure has not been called");
   if (!ctx->det_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_det_configure has not been called");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -617,10 +681,58 @@ int32_t attpc_sim_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint6
     if (kin_status) std::memcpy(kin_status + done, hstatus.data(), (size_t)n * sizeof(int32_t));
     if (p4) HIP_TRY(ctx, hipMemcpy(p4 + done * n_rows * 4, ctx->p4.p, (size_t)n * n_rows * 4 * sizeof(double), hipMemcpyDeviceToHost));
     if (vertex) HIP_TRY(ctx, hipMemcpy(vertex + done * 3, ctx->vertex.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    if (out && (rc = assemble_chunk(ctx, r, n, done, out, &row_cursor, &over))) return rc;
+    if (out) {
+      rc = spyral ? assemble_chunk_spyral(ctx, r, n, done, out, &row_cursor, &over)
+                  : assemble_chunk(ctx, r, n, done, out, &row_cursor, &over);
+      if (rc) return rc;
+    }
   }
+  if (spyral) st.n_points = (uint64_t)row_cursor;  // rows that survive the threshold
   if (stats) *stats = st;
   if (over) return fail(ctx, ATTPC_E_CAPACITY, "cloud needs %lld rows, capacity %lld", (long long)row_cursor, (long long)out->capacity);
+  return ATTPC_OK;
+}
+
+int32_t attpc_sim_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                      const attpc_event_layout* layout, double* p4, double* vertex, int32_t* kin_status,
+                      attpc_cloud_out* out, attpc_run_stats* stats) {
+  return sim_run_impl(ctx, seed, first_event, n_events, layout, p4, vertex, kin_status, out, stats, false);
+}
+
+int32_t attpc_sim_run_spyral(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                             const attpc_event_layout* layout, double* p4, double* vertex, int32_t* kin_status,
+                             attpc_cloud_out* out, attpc_run_stats* stats) {
+  if (!out) return fail(ctx, ATTPC_E_INVALID, "attpc_sim_run_spyral needs output buffers");
+  return sim_run_impl(ctx, seed, first_event, n_events, layout, p4, vertex, kin_status, out, stats, true);
+}
+
+int32_t attpc_spyral_configure(attpc_ctx* ctx, const attpc_spyral_desc* d) {
+  if (!ctx || !d || !d->response || !d->pad_centers || !d->pad_sizes || d->n_pads < 1) return ATTPC_E_INVALID;
+  if (d->windows_edge <= d->micromegas_edge) return fail(ctx, ATTPC_E_INVALID, "windows_edge <= micromegas_edge");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  free_all(ctx->spyral_allocs);
+  ctx->spyral_ready = false;
+  SpyralDev sp{};
+  std::vector<double> sorted(d->response, d->response + ATTPC_NUM_TB);
+  std::sort(sorted.begin(), sorted.end(), [](double a, double b) { return a > b; });
+  std::vector<double> prefix(ATTPC_NUM_TB + 1, 0.0);
+  for (int i = 0; i < ATTPC_NUM_TB; ++i) prefix[i + 1] = prefix[i] + sorted[i];
+  int32_t rc;
+  if ((rc = upload(ctx, ctx->spyral_allocs, d->response, (size_t)ATTPC_NUM_TB, &sp.response))) return rc;
+  if ((rc = upload(ctx, ctx->spyral_allocs, sorted.data(), sorted.size(), &sp.sorted_desc))) return rc;
+  if ((rc = upload(ctx, ctx->spyral_allocs, prefix.data(), prefix.size(), &sp.prefix))) return rc;
+  if ((rc = upload(ctx, ctx->spyral_allocs, d->pad_centers, (size_t)d->n_pads * 2, &sp.pad_centers))) return rc;
+  if ((rc = upload(ctx, ctx->spyral_allocs, d->pad_sizes, (size_t)d->n_pads, &sp.pad_sizes))) return rc;
+  sp.n_pads = d->n_pads;
+  sp.r_max = sorted[0];
+  sp.total = prefix[ATTPC_NUM_TB];
+  sp.window_edge = (double)d->windows_edge;
+  sp.mm_edge = (double)d->micromegas_edge;
+  sp.length = d->length;
+  sp.threshold = d->adc_threshold;
+  ctx->spyral = sp;
+  ctx->spyral_ready = true;
   return ATTPC_OK;
 }
 

@@ -36,4 +36,21 @@ void launch_decay_calculate(hipStream_t s, uint32_t n, const double* parent, dou
 void launch_track_kernel(uint32_t blocks, size_t lds_bytes, hipStream_t s, const TrackArgs& a);
 void launch_scatter_kernel(uint32_t n_events, hipStream_t s, const ScatterArgs& a);
 
+// response + threshold + Spyral rows on device (spyral.hip)
+struct SpyralDev {
+  const double* response;      // [512]
+  const double* sorted_desc;   // [512] response sorted descending
+  const double* prefix;        // [513] prefix sums of sorted_desc (prefix[k] = sum of the k largest)
+  const double* pad_centers;   // [n_pads][2]
+  const double* pad_sizes;     // [n_pads]
+  int32_t n_pads;
+  double r_max, total;
+  double window_edge, mm_edge, length, threshold;
+};
+void launch_spyral_count(hipStream_t s, const SpyralDev& sp, uint32_t n_events, const int64_t* event_start,
+                         const double* points, int32_t* kept);
+void launch_spyral_write(hipStream_t s, const SpyralDev& sp, uint32_t n_events, const int64_t* event_start,
+                         const int64_t* kept_start, const double* points, const int64_t* labels, double* rows,
+                         int64_t* out_labels);
+
 }  // namespace attpc

@@ -120,11 +120,7 @@ class SpyralWriter:
         self.file = self._open(self.run_number)
 
     def write(self, data: np.ndarray, labels: np.ndarray, config: Config, event_number: int) -> None:
-        if self.events_written == self.max_events_per_file:
-            self.close()
-            self.create_next_file()
-            self.starting_event = event_number
-            self.events_written = 0
+        """[P,3] cloud -> Spyral rows (device), ADC threshold, z-sort, datasets (writer.py:194-255)."""
         if config.pad_centers is None:
             raise ValueError("Pad centers are not assigned at write!")
         rows = convert_to_spyral(
@@ -132,8 +128,17 @@ class SpyralWriter:
             config.det_params.length, self.response, config.pad_centers, config.pad_sizes,
         )
         keep = rows[:, 3] > config.elec_params.adc_threshold  # writer.py:232-234
-        rows, labels = rows[keep], labels[keep]
-        order = np.argsort(rows[:, 2])  # writer.py:236-238
+        self.write_rows(rows[keep], labels[keep], event_number)
+
+    def write_rows(self, rows: np.ndarray, labels: np.ndarray, event_number: int) -> None:
+        """Already converted and thresholded rows [P',8] (e.g. from ``Engine.run_spyral``): z-sort
+        (writer.py:236-238), file roll-over (:214-218), datasets and attributes (:240-251)."""
+        if self.events_written == self.max_events_per_file:
+            self.close()
+            self.create_next_file()
+            self.starting_event = event_number
+            self.events_written = 0
+        order = np.argsort(rows[:, 2])
         rows, labels = rows[order], labels[order]
         self.file.create_dataset(
             f"cloud_{event_number}", rows,

@@ -78,3 +78,70 @@ class Engine:
         total = int(offsets[-1])
         return {"vertex": vertex, "p4": p4, "status": status, "offsets": offsets, "points": points[:total],
                 "labels": labels[:total], "stats": stats.as_dict()}
+
+    # ---------------------------------------------------------------- Spyral rows on the device
+    def configure_spyral(self, config=None) -> None:
+        """Upload what SpyralWriter needs (reference writer.py:164-181, 220-234): the GET response of
+        the electronics, pad centres / sizes, ADC threshold and time-bucket edges."""
+        from .detector.response import get_response
+
+        config = config or self.config
+        if config.pad_centers is None:
+            raise ValueError("Pad centers are not assigned at write!")  # writer.py:220-221
+        ctx = self.ctx
+        response = np.ascontiguousarray(get_response(config), dtype=np.float64)
+        centers = np.ascontiguousarray(config.pad_centers, dtype=np.float64)
+        sizes = np.ascontiguousarray(config.pad_sizes, dtype=np.float64)
+        desc = _abi.SpyralDesc(_abi.dptr(response), _abi.dptr(centers), _abi.dptr(sizes), len(sizes),
+                               int(config.elec_params.windows_edge), int(config.elec_params.micromegas_edge), 0,
+                               float(config.det_params.length), float(config.elec_params.adc_threshold))
+        ctx.check(ctx.lib.attpc_spyral_configure(ctx.handle, desc), "attpc_spyral_configure")
+        self._spyral_configured = True
+
+    def run_spyral(self, n_events: int, seed: int = 0, first_event: int = 0, capacity_per_event: int = 6144) -> dict:
+        """Fused kinematics + detector + (on the device) GET response, ADC threshold and Spyral row
+        conversion.  Returns rows [P', 8] (x mm, y mm, z mm, amplitude, integral, pad, tb, pad scale)
+        in CSR form; rows of one event are in cloud order (sort by column 2 for the writer's z order)."""
+        if not getattr(self, "_spyral_configured", False):
+            self.configure_spyral()
+        ctx = self.ctx
+        stats = _abi.RunStats()
+        p4 = np.empty((n_events, self.n_rows, 4), dtype=np.float64)
+        vertex = np.empty((n_events, 3), dtype=np.float64)
+        status = np.empty(n_events, dtype=np.int32)
+        capacity = max(4096, int(capacity_per_event) * int(n_events))
+        while True:
+            offsets = np.zeros(n_events + 1, dtype=np.int64)
+            rows = np.empty((capacity, 8), dtype=np.float64)
+            labels = np.empty(capacity, dtype=np.int64)
+            out = _abi.CloudOut(capacity, _abi.iptr(offsets, _abi.C.c_int64), _abi.dptr(rows),
+                                _abi.iptr(labels, _abi.C.c_int64))
+            rc = ctx.lib.attpc_sim_run_spyral(ctx.handle, int(seed), int(first_event), int(n_events), self.layout,
+                                              _abi.dptr(p4), _abi.dptr(vertex), _abi.iptr(status, _abi.C.c_int32),
+                                              out, stats)
+            if rc == _abi.E_CAPACITY:
+                capacity = int(stats.n_points) + 4096
+                continue
+            ctx.check(rc, "attpc_sim_run_spyral")
+            break
+        total = int(offsets[-1])
+        return {"vertex": vertex, "p4": p4, "status": status, "offsets": offsets, "rows": rows[:total],
+                "labels": labels[:total], "stats": stats.as_dict()}
+
+
+def run_fused(pipeline, config, writer, n_events: int, indices: list[int] | None = None, seed: int | None = None,
+              batch_size: int = 65536, context: _abi.Context | None = None) -> None:
+    """run_kinematics_pipeline + run_simulation + SpyralWriter without the kinematics file and with
+    the response / threshold / row conversion done on the GPU: per non-empty event, in event order,
+    ``writer.write_rows(rows, labels, event_number)`` (rows already thresholded), then ``close()``."""
+    engine = Engine(pipeline, config, indices, context=context)
+    engine.configure_spyral(config)
+    seed = pipeline.seed if seed is None else int(seed)
+    for start in range(0, n_events, batch_size):
+        n = min(batch_size, n_events - start)
+        res = engine.run_spyral(n, seed=seed, first_event=start)
+        off = res["offsets"]
+        for i in range(n):
+            if off[i + 1] > off[i]:
+                writer.write_rows(res["rows"][off[i]:off[i + 1]], res["labels"][off[i]:off[i + 1]], start + i)
+    writer.close()

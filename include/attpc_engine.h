@@ -237,6 +237,31 @@ ATTPC_API int32_t attpc_spyral_rows(attpc_ctx* ctx, int64_t n_points, const doub
                           const double* pad_sizes /*[npads]*/, int32_t n_pads, int32_t windows_edge,
                           int32_t micromegas_edge, double length, double* rows);
 
+/* Electronics / geometry the Spyral conversion needs: get_response(config) (detector/response.py:8-32),
+ * Config.pad_centers / pad_sizes (detector/parameters.py:207-261), adc_threshold, time-bucket edges. */
+typedef struct attpc_spyral_desc {
+  const double* response;    /* [ATTPC_NUM_TB] ADC counts per electron and time bucket */
+  const double* pad_centers; /* [n_pads, 2] mm */
+  const double* pad_sizes;   /* [n_pads] */
+  int32_t n_pads;
+  int32_t windows_edge;
+  int32_t micromegas_edge;
+  int32_t reserved;
+  double length;             /* m */
+  double adc_threshold;      /* rows with amplitude <= threshold are dropped (writer.py:232-234) */
+} attpc_spyral_desc;
+
+ATTPC_API int32_t attpc_spyral_configure(attpc_ctx* ctx, const attpc_spyral_desc* desc);
+
+/* attpc_sim_run followed, on the device and before anything crosses PCIe, by what SpyralWriter.write
+ * does per event (detector/writer.py:194-238): convert_to_spyral (rows of 8: x_mm, y_mm, z_mm,
+ * amplitude, integral, pad, tb, pad_scale) and the ADC-threshold cut.  out->points receives rows of
+ * EIGHT doubles here (capacity counts rows); rows of one event keep their cloud order (the z-sort of
+ * writer.py:236-238 is left to the host writer). */
+ATTPC_API int32_t attpc_sim_run_spyral(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                                       const attpc_event_layout* layout, double* p4, double* vertex,
+                                       int32_t* kin_status, attpc_cloud_out* out, attpc_run_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -495,6 +495,57 @@ def test_reaction_errors_and_config_paths(tmp_path, ctx):
     ctx._det_token = None
 
 
+def test_fused_spyral_rows(tmp_path, ctx, orc):
+    """attpc_sim_run_spyral (response, ADC threshold, row conversion on the device) against
+    (a) the cloud path + convert_to_spyral + threshold and (b) the oracle's convert_to_spyral."""
+    from attpc_engine_amd.detector.response import get_response
+    from attpc_engine_amd.detector.writer import SpyralWriter, convert_to_spyral
+    from attpc_engine_amd.engine import run_fused
+    inp = Inputs("o16aa")
+    eng = _engine(inp, ctx, chunk_events=9)  # several chunks
+    n = 30
+    fused = eng.run_spyral(n, seed=77, first_event=3)
+    cloud = eng.run(n, seed=77, first_event=3, fetch=True)
+    cfg = inp.config
+    resp = get_response(cfg)
+    thr = cfg.elec_params.adc_threshold
+    assert fused["offsets"][-1] < cloud["offsets"][-1]  # the threshold removes rows before D2H
+    L = orc.lib()
+    for e in range(n):
+        lo, hi = cloud["offsets"][e], cloud["offsets"][e + 1]
+        pts, lab = np.ascontiguousarray(cloud["points"][lo:hi]), cloud["labels"][lo:hi]
+        rows = convert_to_spyral(pts, 560, 10, 1.0, resp, cfg.pad_centers, cfg.pad_sizes, ctx=ctx)
+        keep = rows[:, 3] > thr
+        flo, fhi = fused["offsets"][e], fused["offsets"][e + 1]
+        got, got_lab = fused["rows"][flo:fhi], fused["labels"][flo:fhi]
+        assert len(got) == keep.sum()
+        # both are in cloud order of their own run: compare sorted by (pad, tb)
+        o1 = np.lexsort((got[:, 6], got[:, 5]))
+        want, want_lab = rows[keep], lab[keep]
+        o2 = np.lexsort((want[:, 6], want[:, 5]))
+        np.testing.assert_allclose(got[o1], want[o2], rtol=1e-12, atol=0)
+        np.testing.assert_array_equal(got[o1][:, [0, 1, 2, 3, 5, 6, 7]], want[o2][:, [0, 1, 2, 3, 5, 6, 7]])
+        np.testing.assert_array_equal(got_lab[o1], want_lab[o2])
+        if e < 4:  # oracle (sequential 512-sample clipped sum, like the reference's numba loop)
+            ref = np.empty((len(pts), 8))
+            L.orc_convert_to_spyral(_abi.dptr(pts), len(pts), 560, 10, 1.0, _abi.dptr(np.ascontiguousarray(resp)),
+                                    _abi.dptr(np.ascontiguousarray(cfg.pad_centers)),
+                                    _abi.dptr(np.ascontiguousarray(cfg.pad_sizes)), _abi.dptr(ref))
+            np.testing.assert_allclose(want[o2], ref[keep][o2], rtol=1e-12)
+    # writer integration: fused rows -> SpyralWriter.write_rows
+    out_dir = tmp_path / "fused"
+    out_dir.mkdir()
+    run_fused(inp.pipeline, cfg, SpyralWriter(out_dir, cfg, max_events_per_file=16), n, seed=77, context=ctx)
+    files = sorted(out_dir.iterdir())
+    assert len(files) >= 2
+    if files[0].suffix == ".npz":
+        first = np.load(files[0])
+        names = [k for k in first.files if k.startswith("cloud/cloud_") and "@" not in k]
+        assert names
+        rows0 = first[names[0]]
+        assert rows0.shape[1] == 8 and (np.diff(rows0[:, 2]) >= 0).all() and (rows0[:, 3] > thr).all()
+
+
 def test_spyral_rows_golden(golden_dir, ctx):
     from attpc_engine_amd import GasTarget
     from attpc_engine_amd.detector.writer import convert_to_spyral

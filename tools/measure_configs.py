@@ -49,4 +49,14 @@ for name, n in (("be10dp", 100_000), ("o16aa", 200_000), ("b10chain", 50_000)):
         dt = time.perf_counter() - t0
         out["o16aa_delivered_to_host"] = {"events": m, "events_per_s_incl_d2h_and_csr_assembly": m / dt,
                                           "GB_copied": res["points"].nbytes / 1e9 + res["labels"].nbytes / 1e9}
+        del res
+        eng.run_spyral(2000, seed=1)
+        t0 = time.perf_counter()
+        res = eng.run_spyral(m, seed=1)
+        dt = time.perf_counter() - t0
+        out["o16aa_spyral_rows_delivered_to_host"] = {
+            "events": m, "events_per_s_incl_response_threshold_d2h": m / dt,
+            "rows_per_event_after_threshold": len(res["rows"]) / m,
+            "GB_copied": res["rows"].nbytes / 1e9 + res["labels"].nbytes / 1e9}
+        del res
 print(json.dumps(out, indent=1))

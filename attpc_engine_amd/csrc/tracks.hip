@@ -20,8 +20,14 @@
 
 namespace attpc {
 
-constexpr int TRACK_THREADS = 256;
-constexpr int STEPS_PER_REFILL = 4;
+#ifndef ATTPC_TRACK_THREADS
+#define ATTPC_TRACK_THREADS 256
+#endif
+#ifndef ATTPC_TRACK_REFILL
+#define ATTPC_TRACK_REFILL 4
+#endif
+constexpr int TRACK_THREADS = ATTPC_TRACK_THREADS;
+constexpr int STEPS_PER_REFILL = ATTPC_TRACK_REFILL;  // steps between two looks for finished lanes
 
 
 struct Decomp {  // |gamma*beta| decomposition of a state, shared by the RHS and the event tests

@@ -22,6 +22,7 @@ DEDX_SUB = 32
 DEDX_NODES = (DEDX_EMAX - DEDX_EMIN) * DEDX_SUB + 1
 NUM_TB = 512
 TIME_SAMPLES = 10001
+LONG_STEPS = 5
 
 EX_GAUSSIAN, EX_UNIFORM, EX_TABLE = 0, 1, 2
 POLAR_UNIFORM, POLAR_ARBITRARY = 0, 1
@@ -75,6 +76,8 @@ class DetDesc(C.Structure):
         ("lut_n", C.c_int32), ("lut_lo", C.c_int32),
         ("n_species", C.c_int32), ("ode_substeps", C.c_int32),
         ("species", SpeciesDesc * MAX_SPECIES),
+        ("longitudinal_diffusion", C.c_double),
+        ("long_weights", C.c_double * 5),
     ]
 
 

@@ -581,6 +581,8 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
   dv.mpgd_gain = d->mpgd_gain;
   dv.lut_n = d->lut_n; dv.lut_lo = d->lut_lo;
   dv.n_species = d->n_species; dv.ode_substeps = d->ode_substeps > 0 ? d->ode_substeps : 1;
+  dv.longitudinal_diffusion = d->longitudinal_diffusion > 0.0 ? d->longitudinal_diffusion : 0.0;
+  for (int s = 0; s < ATTPC_LONG_STEPS; ++s) dv.long_weights[s] = d->long_weights[s];
   int32_t rc;
   if ((rc = upload(ctx, ctx->det_allocs, d->pad_lut, (size_t)d->lut_n * d->lut_n, &dv.pad_lut))) return rc;
   std::vector<double> tabs((size_t)d->n_species * ATTPC_DEDX_NODES);

@@ -91,6 +91,8 @@ struct DetDev {
   const double* dedx;     // [n_species][ATTPC_DEDX_NODES]
   double mass[ATTPC_MAX_SPECIES];
   int32_t Z[ATTPC_MAX_SPECIES];
+  double longitudinal_diffusion;            // extension, 0 = reference behaviour
+  double long_weights[ATTPC_LONG_STEPS];
 };
 
 // track sample arena: blocks of ARENA_BLK samples, each sample = (x, y, time bucket, electrons)

@@ -84,6 +84,16 @@ constexpr int TARGET_KEYS = HASH_CAP / 2;          // aimed-at table fill: inser
 // micromegas, 15 at tb 256, 28 at tb 511; the measured mean of the headline workload is 14.6.)
 // Windows are cut on the prefix sum of this estimate; the ratio observed/estimated of each
 // flushed window rescales the next one.
+// Drift time of slice `sl` of a sample created at time bucket t: the sample itself without the
+// longitudinal-diffusion extension, else numpy.linspace(t - 3 sigma_l, t + 3 sigma_l, 5)[sl] with
+// sigma_l = sqrt(2 D_l dv t / E) / dv time buckets.
+__device__ __forceinline__ double slice_time(const DetDev& det, double t, int sl, int n_slices) {
+  if (n_slices == 1) return t;
+  const double sigma_l = sqrt(2.0 * det.longitudinal_diffusion * det.dv * t / det.efield) / det.dv;
+  const double lo = t - 3.0 * sigma_l, hi = t + 3.0 * sigma_l;
+  return sl == n_slices - 1 ? hi : (double)sl * ((hi - lo) / (double)(n_slices - 1)) + lo;
+}
+
 __device__ __forceinline__ int key_estimate(int tb, float spread) {
   const float r = 1.0f + sqrtf(spread * (float)tb);
   return (int)fminf(r * r + 0.5f, 100.0f);  // a sample has 100 pixels
@@ -101,6 +111,7 @@ struct __align__(16) ScatterShared {
                                                // the whole array is the slot list during a flush
   double wtab[PIXELS];
   double st_n[STAGE];
+  double st_wl[STAGE];        // longitudinal slice weight (1 without the extension)
   short st_ix[STAGE][MESH];   // LUT row index of mesh line i, -1 = off the pad plane
   short st_iy[STAGE][MESH];
   int st_tb[STAGE];           // bits 0..9 time bucket, 24..26 position in `indices`, 30 point transport
@@ -248,12 +259,18 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
   PHASE_MARK(0);
 
   // ---- histogram of kept samples per time bucket (all nuclei), then its prefix sum ----
+  const int n_slices = a.det.longitudinal_diffusion > 0.0 ? ATTPC_LONG_STEPS : 1;
   for (int c = tid; c < total; c += SC_THREADS) {
     int isim;
     const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
     // t < 0 (sigma_t would be NaN: undefined in the reference) and tb >= 512 (removed by the
     // 0 <= tb < 512 mask of simulator.py:111-113) never reach the output
-    if (t >= 0.0 && t < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)t], key_estimate((int)t, spread));
+    if (!(t >= 0.0)) continue;
+    const int est = key_estimate((int)fmin(t, 511.0), spread);
+    for (int sl = 0; sl < n_slices; ++sl) {
+      const double ts = slice_time(a.det, t, sl, n_slices);
+      if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)ts], est);
+    }
   }
   __syncthreads();
   {  // inclusive prefix sum over the 512 buckets: per-thread serial part, wave scan, wave offsets
@@ -294,18 +311,20 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     PHASE_MARK(2);
 
     // ---- scatter the window's samples of all nuclei, STAGE samples per round ----
-    for (int base = 0; base < total; base += STAGE) {
+    for (int base = 0; base < total * n_slices; base += STAGE) {
       if (tid == 0) sh.n_stage = 0;
       __syncthreads();
       // stage
-      const int c = base + tid;
-      if (tid < STAGE && c < total) {
+      const int cs = base + tid;  // (sample, slice) index
+      if (tid < STAGE && cs < total * n_slices) {
+        const int c = cs / n_slices, sl = cs - c * n_slices;
         int isim;
         const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
         const double2 tn = reinterpret_cast<const double2*>(rec)[1];
         const double t = tn.x;
-        if (t >= 0.0 && t < (double)ATTPC_NUM_TB) {
-          const int tb = (int)t;  // transporter.py:238
+        const double ts = t >= 0.0 ? slice_time(a.det, t, sl, n_slices) : -1.0;
+        if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
+          const int tb = (int)ts;  // transporter.py:238
           if (tb >= win_a && tb < win_b) {
             const double2 xy = reinterpret_cast<const double2*>(rec)[0];
             const int slot = atomicAdd(&sh.n_stage, 1);
@@ -325,6 +344,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
               sh.st_iy[slot][i] = (fy >= lo_mm && fy < hi_mm) ? (short)((int)fy - lut_lo) : (short)-1;
             }
             sh.st_n[slot] = tn.y;
+            sh.st_wl[slot] = n_slices == 1 ? 1.0 : a.det.long_weights[sl];
             sh.st_tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
           }
         }
@@ -350,6 +370,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
           const bool point = (tbw & (1 << 30)) != 0;
           const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
           const double n_el = sh.st_n[st];
+          const double wl = sh.st_wl[st];
           const int ix = sh.st_ix[st][i];
           // point_transport (transporter.py:123-169): all electrons straight down.  With
           // sigma == 0 every mesh line sits on the centre: row 0, pixel 0 stand for the sample.
@@ -377,7 +398,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
 #pragma unroll
             for (int j = 0; j < MESH; ++j) {
               const double w = point ? 1.0 : sh.wtab[i * MESH + j];
-              const double t = trunc(w * n_el);
+              const double t = trunc((w * wl) * n_el);  // wl == 1 exactly without the extension
               acc += raw[j] >= 0 ? t : 0.0;
               const bool last = (j == MESH - 1) || (raw[j < MESH - 1 ? j + 1 : j] != raw[j]);
               run_q[j] = acc;
@@ -393,7 +414,7 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
               for (int j = 0; j < MESH && ok; ++j) {
                 const int iy = sh.st_iy[st][j];
                 const int pad = (live && iy >= 0 && (!point || j == 0)) ? (int)lut_row[max(iy, 0)] : -1;
-                if (pad >= 0) ok = table_add(sh, word_hi | (uint32_t)pad, (unsigned long long)((point ? 1.0 : sh.wtab[i * MESH + j]) * n_el));
+                if (pad >= 0) ok = table_add(sh, word_hi | (uint32_t)pad, (unsigned long long)(((point ? 1.0 : sh.wtab[i * MESH + j]) * wl) * n_el));
               }
             }
           }

@@ -63,6 +63,13 @@ def fold_beam_pads(lut: np.ndarray) -> np.ndarray:
     return out
 
 
+def longitudinal_weights() -> np.ndarray:
+    """Charge fraction of the 5 time slices of the longitudinal-diffusion extension: 1-D Gaussian
+    pdf x slice pitch at linspace(-3 sigma, 3 sigma, 5) (pitch 1.5 sigma), independent of sigma."""
+    d = np.arange(_abi.LONG_STEPS) - (_abi.LONG_STEPS - 1) / 2.0
+    return 1.5 / np.sqrt(2.0 * np.pi) * np.exp(-1.125 * d * d)
+
+
 def build_det_desc(config, nuclei: list, ode_substeps: int = 1, fold_beam: bool = True):
     """-> (DetDesc, keepalive).  ``nuclei``: species table (objects with Z, A, mass)."""
     if config.pad_grid_edges is None or config.pad_grid is None:
@@ -92,6 +99,9 @@ def build_det_desc(config, nuclei: list, ode_substeps: int = 1, fold_beam: bool 
     desc.lut_lo = k_min
     desc.n_species = len(nuclei)
     desc.ode_substeps = int(ode_substeps)
+    desc.longitudinal_diffusion = float(getattr(det, "longitudinal_diffusion", 0.0) or 0.0)
+    for s, w in enumerate(longitudinal_weights()):
+        desc.long_weights[s] = w
     for i, nuc in enumerate(nuclei):
         table = sample_dedx_table(det.gas_target, nuc)
         keep.append(table)

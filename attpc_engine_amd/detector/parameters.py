@@ -24,7 +24,10 @@ DEFAULT = "Default"
 @dataclass
 class DetectorParams:
     """length [m], efield [V/m], bfield [T], mpgd_gain, gas_target (``get_dedx``/``density``),
-    diffusion [V], fano_factor, w_value [eV] -- reference parameters.py:10-48."""
+    diffusion [V], fano_factor, w_value [eV] -- reference parameters.py:10-48.
+
+    ``longitudinal_diffusion`` [V] is an opt-in EXTENSION (the reference has no longitudinal
+    diffusion, docs/user_guide/detector/index.md:130-133); 0 keeps the reference behaviour."""
 
     length: float
     efield: float
@@ -34,6 +37,7 @@ class DetectorParams:
     diffusion: float
     fano_factor: float
     w_value: float
+    longitudinal_diffusion: float = 0.0
 
 
 @dataclass

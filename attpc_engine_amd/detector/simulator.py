@@ -34,7 +34,10 @@ def _nuclear_map():
 def configure_detector(config: Config, species_keys: list[tuple[int, int]], ctx: _abi.Context,
                        ode_substeps: int = 1) -> None:
     """Upload Config + species tables unless this ctx already holds the same ones."""
-    token = (id(config), tuple(species_keys), ode_substeps, config.drift_velocity)
+    dp = config.det_params
+    token = (id(config), tuple(species_keys), ode_substeps, config.drift_velocity, dp.length, dp.efield,
+             dp.bfield, dp.mpgd_gain, id(dp.gas_target), dp.diffusion, dp.fano_factor, dp.w_value,
+             getattr(dp, "longitudinal_diffusion", 0.0))
     if getattr(ctx, "_det_token", None) == token:
         return
     nuclei = [_nuclear_map().get_data(z, a) for (z, a) in species_keys]

@@ -53,6 +53,7 @@ extern "C" {
 #define ATTPC_NUM_TB 512        /* detector/constants.py:23                                 */
 #define ATTPC_TIME_SAMPLES 10001 /* detector/solver.py:16  TIME_STEPS                       */
 #define ATTPC_MESH_STEPS 10     /* detector/transporter.py:8  STEPS                         */
+#define ATTPC_LONG_STEPS 5      /* time slices of the longitudinal-diffusion extension       */
 
 /* excitation sampler kinds -- kinematics/excitation.py */
 #define ATTPC_EX_GAUSSIAN 0 /* p0 = centroid, p1 = sigma (= FWHM/2.355)         :32-80      */
@@ -128,6 +129,13 @@ typedef struct attpc_det_desc {
   int32_t n_species;
   int32_t ode_substeps; /* RK4 sub-steps per 1e-10 s output sample; 0 -> default (1) */
   attpc_species_desc species[ATTPC_MAX_SPECIES];
+  /* EXTENSION (not in the reference, which has no longitudinal diffusion -- docs/user_guide/
+     detector/index.md:130-133): > 0 spreads every sample over ATTPC_LONG_STEPS time slices,
+     linspace(t - 3 sigma_l, t + 3 sigma_l), sigma_l = sqrt(2 D_l dv t / E) / dv time buckets,
+     slice s carrying the fraction long_weights[s] (1-D Gaussian pdf x slice pitch) of each
+     pixel: electrons = int(pdf h^2 * long_weights[s] * n).  0 = reference behaviour. */
+  double longitudinal_diffusion; /* V */
+  double long_weights[5];
 } attpc_det_desc;
 
 /* which rows of an event are simulated, detector/simulator.py:96-101,157-158 */

@@ -504,19 +504,19 @@ static void linspace10(double lo, double hi, double out[ORC_MESH_STEPS]) {
 
 /* detector/transporter.py:123-169 */
 static void point_transport(const orc_det_desc* det, double time, double cx, double cy, int64_t electrons,
-                            orc_dict* points, int64_t label) {
+                            orc_dict* points, int64_t label, double wl) {
   int64_t ix, iy;
   if (!position_to_index(det, cx, cy, &ix, &iy)) return;
   int64_t pad = det->pad_lut[ix * det->lut_n + iy];
   if (pad != -1 && !is_beam_pad(pad)) {
     int64_t tb = (int64_t)time;
-    dict_add(points, orc_pair(tb, pad), electrons, label);
+    dict_add(points, orc_pair(tb, pad), wl == 1.0 ? electrons : (int64_t)(wl * (double)electrons), label);
   }
 }
 
 /* detector/transporter.py:172-249 */
 static void transverse_transport(const orc_det_desc* det, double time, double cx, double cy,
-                                 int64_t electrons, double sigma_t, orc_dict* points, int64_t label) {
+                                 int64_t electrons, double sigma_t, orc_dict* points, int64_t label, double wl) {
   double xs[ORC_MESH_STEPS], ys[ORC_MESH_STEPS];
   linspace10(cx - 3.0 * sigma_t, cx + 3.0 * sigma_t, xs);
   linspace10(cy - 3.0 * sigma_t, cy + 3.0 * sigma_t, ys);
@@ -531,7 +531,7 @@ static void transverse_transport(const orc_det_desc* det, double time, double cx
         int64_t tb = (int64_t)time;
         int64_t id = orc_pair(tb, pad);
         int64_t pixel =
-            (int64_t)(bivariate_normal_pdf(xs[i], ys[j], cx, cy, sigma_t) * (step_x * step_y) * (double)electrons);
+            (int64_t)(bivariate_normal_pdf(xs[i], ys[j], cx, cy, sigma_t) * (step_x * step_y) * wl * (double)electrons);
         dict_add(points, id, pixel, label);
       }
     }
@@ -545,9 +545,21 @@ void orc_transport_track(const orc_det_desc* det, const double* xyt, const int64
   for (int32_t i = 0; i < n; ++i) {
     double time = xyt[3 * i + 2];
     double sigma_t = sqrt(2.0 * det->diffusion * dv * time / det->efield);
-    if (sigma_t == 0.0) point_transport(det, time, xyt[3 * i], xyt[3 * i + 1], electrons[i], points, label);
-    else if (sigma_t == sigma_t) /* NaN (time < 0) is undefined behaviour in the reference: dropped */
-      transverse_transport(det, time, xyt[3 * i], xyt[3 * i + 1], electrons[i], sigma_t, points, label);
+    if (!(sigma_t == sigma_t)) continue; /* NaN (time < 0) is undefined behaviour in the reference: dropped */
+    if (det->longitudinal_diffusion > 0.0) {
+      /* EXTENSION: 5 time slices over +-3 sigma_l (numpy.linspace semantics), weight long_weights[s] */
+      double sigma_l = sqrt(2.0 * det->longitudinal_diffusion * dv * time / det->efield) / dv;
+      double lo = time - 3.0 * sigma_l, hi = time + 3.0 * sigma_l, step = (hi - lo) / 4.0;
+      for (int sl = 0; sl < 5; ++sl) {
+        double ts = sl == 4 ? hi : (double)sl * step + lo;
+        if (!(ts >= 0.0)) continue;
+        if (sigma_t == 0.0) point_transport(det, ts, xyt[3 * i], xyt[3 * i + 1], electrons[i], points, label, det->long_weights[sl]);
+        else transverse_transport(det, ts, xyt[3 * i], xyt[3 * i + 1], electrons[i], sigma_t, points, label, det->long_weights[sl]);
+      }
+      continue;
+    }
+    if (sigma_t == 0.0) point_transport(det, time, xyt[3 * i], xyt[3 * i + 1], electrons[i], points, label, 1.0);
+    else transverse_transport(det, time, xyt[3 * i], xyt[3 * i + 1], electrons[i], sigma_t, points, label, 1.0);
   }
 }
 

@@ -72,6 +72,8 @@ typedef struct {
   int32_t lut_n, lut_lo;
   int32_t n_species, ode_substeps;
   orc_species_desc species[ORC_MAX_SPECIES];
+  double longitudinal_diffusion; /* extension, 0 = reference behaviour */
+  double long_weights[5];
 } orc_det_desc;
 
 typedef struct {

@@ -270,6 +270,39 @@ def test_zero_diffusion_and_skipped_rows(ctx, orc):
     ctx._det_token = None
 
 
+@pytest.mark.parametrize("name,d_l", [("o16aa", 0.3), ("be10dp", 0.05), ("be10dp", -1.0)])
+def test_longitudinal_extension_vs_oracle(ctx, orc, name, d_l):
+    """Opt-in longitudinal diffusion (extension): 5 time slices per sample, GPU vs oracle;
+    d_l = -1 also switches the transverse diffusion off (point transport of every slice)."""
+    from attpc_engine_amd.detector.simulator import simulate_batch
+    inp = Inputs(name)
+    inp.config.det_params.longitudinal_diffusion = abs(d_l)
+    if d_l < 0:
+        inp.config.det_params.diffusion = 0.0
+    nuclei = [nuclear_map.get_data(z, a) for z, a in inp.species]
+    from attpc_engine_amd.detector.luts import build_det_desc
+    det_raw, keep = build_det_desc(inp.config, nuclei, fold_beam=False)
+    assert det_raw.longitudinal_diffusion == abs(d_l)
+    seed, first, n = 19, 2, 12
+    vertex, p4, _, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
+    ctx._det_token = None
+    offsets, points, labels, stats = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, seed, inp.indices,
+                                                    first_event=first, ctx=ctx)
+    ctx._det_token = None
+    assert stats["n_failed"] == 0
+    base = Inputs(name)
+    total_ref = 0
+    for e in range(n):
+        ref_pts, ref_lab, _ = orc.simulate(det_raw, inp.layout, seed, first + e, p4[e], vertex[e], capacity=1 << 20)
+        a = sort_cloud(points[offsets[e]:offsets[e + 1]], labels[offsets[e]:offsets[e + 1]])
+        compare_clouds(*a, *sort_cloud(ref_pts, ref_lab))
+        total_ref += len(ref_pts)
+    plain = sum(len(orc.simulate(base.det_raw, base.layout, seed, first + e, p4[e], vertex[e], capacity=1 << 20)[0])
+                for e in range(n)) if d_l > 0 else 0
+    assert offsets[-1] == total_ref and total_ref > plain
+    print(name, d_l, "points", total_ref, "vs", plain, "without the extension", stats)
+
+
 @pytest.mark.parametrize("name,n", [("o16aa", 48), ("be10dp", 48)])
 def test_sim_run_vs_oracle(ctx, orc, name, n):
     """Fused kinematics + detector (attpc_sim_run) vs the oracle's fused batch, incl. CSR."""

@@ -317,3 +317,44 @@ def test_oracle_event_properties():
         lo, hi = a["offsets"][e], a["offsets"][e + 1]
         key = pts[lo:hi, 0].astype(np.int64) * 1024 + np.floor(pts[lo:hi, 1]).astype(np.int64)
         assert len(np.unique(key)) == hi - lo
+
+
+def test_longitudinal_extension_oracle():
+    """Opt-in longitudinal diffusion (no reference counterpart: 'parity unpinned', checked against
+    its own definition): a sample at time t becomes 5 slices at linspace(t - 3 s, t + 3 s, 5) with
+    weights pdf * pitch; D_l = 0 is byte-identical to the reference path."""
+    from attpc_engine_amd.detector.luts import build_det_desc, longitudinal_weights
+    from attpc_engine_amd.detector.pairing import unpair
+    inp = Inputs("o16aa")
+    nuclei = [nuclear_map.get_data(z, a) for z, a in inp.species]
+    w = longitudinal_weights()
+    assert abs(w.sum() - 1.0) < 1e-3 and np.all(w[:2] == w[:2:-1])
+    xyt = np.array([[0.05, 0.03, 200.25], [-0.1, 0.02, 40.5], [0.0, 0.1, 0.4], [0.02, 0.02, 510.9]])
+    elec = np.array([200000, 150000, 90000, 120000], dtype=np.int64)
+    base = orc.transport(inp.det_raw, [(xyt, elec, 2)])
+    inp.config.det_params.longitudinal_diffusion = 0.0
+    det0, k0 = build_det_desc(inp.config, nuclei, fold_beam=False)
+    same = orc.transport(det0, [(xyt, elec, 2)])
+    for a, b in zip(base, same):
+        np.testing.assert_array_equal(a, b)
+    inp.config.det_params.longitudinal_diffusion = 0.3
+    det1, k1 = build_det_desc(inp.config, nuclei, fold_beam=False)
+    keys, charge, labels = orc.transport(det1, [(xyt, elec, 2)])
+    # one sample at a time: the slices are the D_l = 0 transport of the same (x, y) at the slice
+    # times with the transverse sigma of the ORIGINAL time -> same pad set per occupied bucket
+    cfg = inp.config
+    dv = cfg.drift_velocity
+    for row, n in zip(xyt, elec):
+        k1s, c1s, _ = orc.transport(det1, [(row[None], np.array([n]), 2)])
+        k0s, c0s, _ = orc.transport(det0, [(row[None], np.array([n]), 2)])
+        tb1, pad1 = np.array([unpair(int(k)) for k in k1s]).T
+        tb0, pad0 = np.array([unpair(int(k)) for k in k0s]).T
+        sig = np.sqrt(2.0 * 0.3 * dv * row[2] / cfg.det_params.efield) / dv
+        ts = np.linspace(row[2] - 3 * sig, row[2] + 3 * sig, 5)
+        expect_tb = sorted({int(t) for t in ts if t >= 0.0})  # tb >= 512 is masked later, in simulate()
+        assert sorted(set(tb1.tolist())) == expect_tb
+        for tb in expect_tb:
+            assert set(pad1[tb1 == tb].tolist()) <= set(pad0.tolist())
+        wsum = sum(wi for wi, t in zip(w, ts) if t >= 0.0)
+        assert 0.9 * wsum * c0s.sum() < c1s.sum() <= wsum * c0s.sum() * 1.001
+    assert len(keys) > len(base[0]) and set(labels.tolist()) == {2}

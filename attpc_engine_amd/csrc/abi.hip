@@ -198,7 +198,7 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 
     uint32_t tctrl[4];
-    unsigned long long octrl[24];
+    unsigned long long octrl[32];
     HIP_TRY(ctx, hipMemcpyAsync(tctrl, ctx->trk_ctrl.p, sizeof tctrl, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(octrl, ctx->out_ctrl.p, sizeof octrl, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -222,6 +222,8 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
     fprintf(stderr, "[attpc phase cycles] init %llu hist %llu select %llu stage %llu items %llu overflow %llu flushcount %llu flushwrite %llu (events %u)\n",
             octrl[8], octrl[9], octrl[10], octrl[11], octrl[12], octrl[13], octrl[14], octrl[15], n);
     fprintf(stderr, "[attpc rows-phase cycles] gathers %llu runs %llu scan+queue %llu drain %llu\n", octrl[16], octrl[17], octrl[18], octrl[19]);
+    fprintf(stderr, "[attpc rounds] rows-rounds %llu staged %llu busiest-wave passes %llu\n", octrl[20], octrl[21], octrl[22]);
+    fprintf(stderr, "[attpc flush cycles] to-compacted %llu atomics-wait %llu segment %llu select %llu barrier %llu\n", octrl[23], octrl[24], octrl[25], octrl[26], octrl[14]);
     fprintf(stderr, "[attpc ctrl] rows %llu segments %llu failed %llu retried %llu samples %llu\n", octrl[0], octrl[1],
             octrl[4], octrl[5], octrl[7]);
 #endif
@@ -584,7 +586,15 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
   dv.longitudinal_diffusion = d->longitudinal_diffusion > 0.0 ? d->longitudinal_diffusion : 0.0;
   for (int s = 0; s < ATTPC_LONG_STEPS; ++s) dv.long_weights[s] = d->long_weights[s];
   int32_t rc;
-  if ((rc = upload(ctx, ctx->det_allocs, d->pad_lut, (size_t)d->lut_n * d->lut_n, &dv.pad_lut))) return rc;
+  {  // device copy is TRANSPOSED ([iy][ix]): the scatter kernel's lanes are mesh rows (one ix each) that
+     // step through iy together, so one gather instruction then reads neighbouring ix of the same
+     // iy row -- 1-2 cache lines per sample instead of one per lane
+    const size_t n = (size_t)d->lut_n;
+    std::vector<int16_t> lut_t(n * n);
+    for (size_t ix = 0; ix < n; ++ix)
+      for (size_t iy = 0; iy < n; ++iy) lut_t[iy * n + ix] = d->pad_lut[ix * n + iy];
+    if ((rc = upload(ctx, ctx->det_allocs, lut_t.data(), n * n, &dv.pad_lut))) return rc;
+  }
   std::vector<double> tabs((size_t)d->n_species * ATTPC_DEDX_NODES);
   for (int s = 0; s < d->n_species; ++s) {
     if (!d->species[s].dedx) return fail(ctx, ATTPC_E_INVALID, "species %d: missing dE/dx table", s);

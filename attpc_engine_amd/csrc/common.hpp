@@ -26,12 +26,22 @@ constexpr uint32_t KIN_SLOTS = 64u;
 // Philox4x32-10 (Salmon et al. SC'11), the algorithm of rocRAND's default generator, written
 // out so that the counter layout (event id, draw index, domain) is ours and the plain-C
 // oracle reproduces the identical stream.
+// 32 x 32 -> 64 bit product in ONE v_mad_u64_u32: the compiler emits v_mul_hi_u32 + v_mul_lo_u32
+// for __umulhi(a, b) and a * b, which makes Philox 1.37x slower on gfx950 (tools/microbench).
+__device__ __forceinline__ void mul_hi_lo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
+  unsigned long long prod, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(prod), "=s"(carry) : "v"(a), "v"(b));
+  hi = (uint32_t)(prod >> 32);
+  lo = (uint32_t)prod;
+}
+
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t hi0, lo0, hi1, lo1;
+    mul_hi_lo(c0, 0xD2511F53u, hi0, lo0);
+    mul_hi_lo(c2, 0xCD9E8D57u, hi1, lo1);
     const uint32_t n0 = hi1 ^ c1 ^ k0;
     const uint32_t n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -85,7 +95,7 @@ struct DetDev {
   double dv;              // drift velocity, m / time bucket (parameters.py:172-174)
   double mm_edge;
   int64_t mpgd_gain;
-  const int16_t* pad_lut; // folded whole-mm LUT
+  const int16_t* pad_lut; // folded whole-mm LUT, transposed: pad_lut[iy * lut_n + ix]
   int32_t lut_n, lut_lo;
   int32_t n_species, ode_substeps;
   const double* dedx;     // [n_species][ATTPC_DEDX_NODES]

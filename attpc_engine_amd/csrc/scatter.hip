@@ -40,7 +40,7 @@ namespace attpc {
 // Diagnostic build only (-DATTPC_PHASE_TIMERS): thread 0 of every workgroup accumulates
 // s_memtime deltas per phase into out.ctrl[8 + phase]; never compiled into the shipped library.
 #ifdef ATTPC_PHASE_TIMERS
-#define PHASE_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(), ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PHASE_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(), ph_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PHASE_MARK(k)                                               \
   do {                                                              \
     const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); \
@@ -48,15 +48,17 @@ namespace attpc {
     ph_t0 = ph_now;                                                 \
   } while (0)
 #define PHASE_SYNC asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define PHASE_COUNT(k, v) ph_acc[k] += (unsigned long long)(v)
 #define PHASE_FLUSH                                                          \
   do {                                                                       \
     if (tid == 0)                                                            \
-      for (int k = 0; k < 12; ++k) atomicAdd(&a.out.ctrl[8 + k], ph_acc[k]); \
+      for (int k = 0; k < 20; ++k) atomicAdd(&a.out.ctrl[8 + k], ph_acc[k]); \
   } while (0)
 #else
 #define PHASE_DECL
 #define PHASE_MARK(k)
 #define PHASE_SYNC
+#define PHASE_COUNT(k, v)
 #define PHASE_FLUSH
 #endif
 
@@ -73,11 +75,20 @@ constexpr int SC_THREADS = ATTPC_SC_THREADS;
 constexpr int STAGE = ATTPC_SC_STAGE;       // samples examined per round
 constexpr int HASH_BITS = ATTPC_SC_HASH_BITS;
 constexpr int HASH_CAP = 1 << HASH_BITS;    // slots
-constexpr int WAVE_QUEUE = 256;             // queued runs per wave and pass (typ. ~190 per 64 mesh rows)
+#ifndef ATTPC_SC_WAVE_QUEUE
+#define ATTPC_SC_WAVE_QUEUE 256
+#endif
+#ifndef ATTPC_SC_WG_PER_CU
+#define ATTPC_SC_WG_PER_CU 1
+#endif
+constexpr int WAVE_QUEUE = ATTPC_SC_WAVE_QUEUE;  // queued runs per wave and pass (typ. ~190 per 64 mesh rows)
 constexpr int N_WAVES = SC_THREADS / 64;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;
-constexpr int TARGET_KEYS = HASH_CAP / 2;          // aimed-at table fill: insert cost rises steeply beyond ~55 %
+#ifndef ATTPC_SC_TARGET_PCT
+#define ATTPC_SC_TARGET_PCT 50
+#endif
+constexpr int TARGET_KEYS = HASH_CAP * ATTPC_SC_TARGET_PCT / 100;          // aimed-at table fill: insert cost rises steeply beyond ~55 %
 // Estimated distinct keys a sample adds: its mesh is 6 sigma_t wide, pads have a ~4.9 mm pitch,
 // so it touches about (1 + 6 sigma_t / 4.9 mm)^2 pads; sigma_t^2 = 2 D dv tb / E.  `spread` =
 // (6 / 4.9 mm)^2 * 2 D dv / E is a per-configuration constant.  (Default detector: 3 keys at the
@@ -116,10 +127,13 @@ struct __align__(16) ScatterShared {
   short st_iy[STAGE][MESH];
   int st_tb[STAGE];           // bits 0..9 time bucket, 24..26 position in `indices`, 30 point transport
   int blocks[ATTPC_MAX_SIM][MAX_BLOCKS_PER_TRACK];  // arena block ids of the event's tracks
+  long long label_of[ATTPC_MAX_SIM];  // row number (label) of each simulated nucleus
   int cnt[ATTPC_MAX_SIM + 1]; // exclusive prefix of kept samples per simulated nucleus
-  int cum[ATTPC_NUM_TB];      // inclusive prefix sum of estimated keys per time bucket
-  int wave_sum[SC_THREADS / 64];
-  int win_a, win_b, win_samples, budget, n_stage, overflow, done, failed, retried;
+  unsigned long long cum[ATTPC_NUM_TB];  // inclusive prefix sums per time bucket: low word estimated keys,
+                                         // high word staged entries (samples x slices)
+  unsigned long long wave_sum[SC_THREADS / 64];
+  int stage_sum[2][SC_THREADS / 64];  // in-window entries per wave of a staging chunk (double buffered)
+  int win_a, win_b, win_samples, budget, overflow, done, failed, retried;
   unsigned int wg_cursor, n_keys;
   unsigned long long base;
   unsigned long long charge_sum, key_sum;
@@ -144,11 +158,14 @@ __device__ __forceinline__ void clear_table(ScatterShared& sh) {
   }
 }
 
-// first index in [lo, hi) with cum[i] > value (cum nondecreasing)
-__device__ __forceinline__ int upper_bound(const int* cum, int lo, int hi, int value) {
+// first index in [lo, hi) whose prefix sum exceeds value; HIGH selects the entry count (high word)
+// instead of the estimated keys (low word)
+template <bool HIGH>
+__device__ __forceinline__ int upper_bound(const unsigned long long* cum, int lo, int hi, unsigned int value) {
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
-    if (cum[mid] > value) hi = mid; else lo = mid + 1;
+    const unsigned int v = HIGH ? (unsigned int)(cum[mid] >> 32) : (unsigned int)cum[mid];
+    if (v > value) hi = mid; else lo = mid + 1;
   }
   return lo;
 }
@@ -202,22 +219,32 @@ __device__ __forceinline__ bool table_add(ScatterShared& sh, uint32_t want, unsi
 }
 
 // Next window [win_a, win_b) of time buckets: starts at the first non-empty bucket >= `from` and
-// extends while the estimated key count stays within the budget (at least one bucket).  Thread 0.
+// extends while the estimated key count stays within the budget (at least one bucket).  A window
+// that does not reach the end of the event is then cut back to a whole number of row passes: the
+// rows phase works in passes of SC_THREADS mesh rows (64 per wave), a window of 2.2 passes costs 3,
+// so the 0.2 is left to the next window.  Thread 0.
 __device__ __forceinline__ void select_window(ScatterShared& sh, int from) {
-  const int before = from > 0 ? sh.cum[from - 1] : 0;
-  const int a0 = upper_bound(sh.cum, from, ATTPC_NUM_TB, before);
+  const unsigned long long before = from > 0 ? sh.cum[from - 1] : 0ull;
+  const unsigned int keys0 = (unsigned int)before, entries0 = (unsigned int)(before >> 32);
+  const int a0 = upper_bound<true>(sh.cum, from, ATTPC_NUM_TB, entries0);
   if (a0 >= ATTPC_NUM_TB) {
     sh.done = 1;
     return;
   }
-  int b0 = upper_bound(sh.cum, a0, ATTPC_NUM_TB, before + sh.budget);
+  int b0 = upper_bound<false>(sh.cum, a0, ATTPC_NUM_TB, keys0 + (unsigned int)sh.budget);
   if (b0 <= a0) b0 = a0 + 1;
+  const unsigned int entries = (unsigned int)(sh.cum[b0 - 1] >> 32) - entries0;
+  const unsigned int passes = entries * MESH / SC_THREADS;
+  if (passes >= 1u && (unsigned int)(sh.cum[ATTPC_NUM_TB - 1] >> 32) > entries0 + entries) {
+    const int b1 = upper_bound<true>(sh.cum, a0, b0, entries0 + passes * SC_THREADS / MESH);
+    if (b1 > a0) b0 = b1;
+  }
   sh.win_a = a0;
   sh.win_b = b0;
-  sh.win_samples = sh.cum[b0 - 1] - before;
+  sh.win_samples = (int)((unsigned int)sh.cum[b0 - 1] - keys0);
 }
 
-__global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
+__global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_kernel(ScatterArgs a) {
   __shared__ ScatterShared sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -236,7 +263,8 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     const double di = (double)(p / MESH) - 4.5, dj = (double)(p % MESH) - 4.5;
     sh.wtab[p] = (36.0 / 81.0) / TWO_PI * exp(-(2.0 / 9.0) * (di * di + dj * dj));
   }
-  for (int i = tid; i < ATTPC_NUM_TB; i += SC_THREADS) sh.cum[i] = 0;
+  for (int i = tid; i < ATTPC_NUM_TB; i += SC_THREADS) sh.cum[i] = 0ull;
+  if (tid < ATTPC_MAX_SIM) sh.label_of[tid] = (long long)a.layout.indices[tid];
   if (tid == 0) {
     int acc = 0;
     for (int k = 0; k < n_sim; ++k) {
@@ -269,27 +297,27 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     const int est = key_estimate((int)fmin(t, 511.0), spread);
     for (int sl = 0; sl < n_slices; ++sl) {
       const double ts = slice_time(a.det, t, sl, n_slices);
-      if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)ts], est);
+      if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)ts], (1ull << 32) | (unsigned long long)est);
     }
   }
   __syncthreads();
   {  // inclusive prefix sum over the 512 buckets: per-thread serial part, wave scan, wave offsets
-    int local[BINS_PER_THREAD];
-    int v = 0;
+    unsigned long long local[BINS_PER_THREAD];
+    unsigned long long v = 0ull;
 #pragma unroll
     for (int k = 0; k < BINS_PER_THREAD; ++k) {
       const int bin = tid * BINS_PER_THREAD + k;
-      v += bin < ATTPC_NUM_TB ? sh.cum[bin] : 0;
+      v += bin < ATTPC_NUM_TB ? sh.cum[bin] : 0ull;
       local[k] = v;
     }
-    int incl = v;
+    unsigned long long incl = v;
     for (int off = 1; off < 64; off <<= 1) {
-      const int up = __shfl_up(incl, off);
-      incl += lane >= off ? up : 0;
+      const unsigned long long up = __shfl_up(incl, off);
+      incl += lane >= off ? up : 0ull;
     }
     if (lane == 63) sh.wave_sum[tid >> 6] = incl;
     __syncthreads();
-    int offset = incl - v;
+    unsigned long long offset = incl - v;
     for (int w = 0; w < (tid >> 6); ++w) offset += sh.wave_sum[w];
 #pragma unroll
     for (int k = 0; k < BINS_PER_THREAD; ++k) {
@@ -310,155 +338,194 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     const int win_a = sh.win_a, win_b = sh.win_b;
     PHASE_MARK(2);
 
-    // ---- scatter the window's samples of all nuclei, STAGE samples per round ----
-    for (int base = 0; base < total * n_slices; base += STAGE) {
-      if (tid == 0) sh.n_stage = 0;
-      __syncthreads();
-      // stage
-      const int cs = base + tid;  // (sample, slice) index
-      if (tid < STAGE && cs < total * n_slices) {
-        const int c = cs / n_slices, sl = cs - c * n_slices;
-        int isim;
-        const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
-        const double2 tn = reinterpret_cast<const double2*>(rec)[1];
-        const double t = tn.x;
-        const double ts = t >= 0.0 ? slice_time(a.det, t, sl, n_slices) : -1.0;
-        if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
-          const int tb = (int)ts;  // transporter.py:238
-          if (tb >= win_a && tb < win_b) {
-            const double2 xy = reinterpret_cast<const double2*>(rec)[0];
-            const int slot = atomicAdd(&sh.n_stage, 1);
-            const double sigma = sqrt(2.0 * a.det.diffusion * a.det.dv * t / a.det.efield);  // :301
-            const double lo_mm = (double)lut_lo, hi_mm = (double)(lut_lo + lut_n);
-            // numpy.linspace(c - 3 sigma, c + 3 sigma, 10) (:221-227) and position_to_index
-            // (:107-118: whole-mm floor, low edge inclusive, high edge exclusive) per mesh line
-            const double xlo = xy.x - 3.0 * sigma, xhi = xy.x + 3.0 * sigma;
-            const double ylo = xy.y - 3.0 * sigma, yhi = xy.y + 3.0 * sigma;
-            const double sx = (xhi - xlo) / (double)(MESH - 1), sy = (yhi - ylo) / (double)(MESH - 1);
+    // ---- scatter the window's samples of all nuclei ----
+    // The (sample, slice) list is scanned in chunks of one entry per thread; the entries inside
+    // the window are ranked (ballot prefix + wave totals) and staged densely, so a rows round runs
+    // on a full staging buffer (or on the window's remainder) whatever the order of the samples.
+    const int total_s = total * n_slices;
+    int round_lo = 0;  // rank of staging slot 0
+    int filled = 0;    // in-window entries of the chunks before this one
+    bool stop = false;
+    // one (sample, slice) entry -> staging slot: sigma_t and the LUT indices of its 20 mesh lines
+    auto stage_entry = [&](int slot, double2 xy, double2 tn, int isim, int sl) {
+      const int tb = (int)slice_time(a.det, tn.x, sl, n_slices);  // transporter.py:238
+      const double sigma = sqrt(2.0 * a.det.diffusion * a.det.dv * tn.x / a.det.efield);  // :301
+      const double lo_mm = (double)lut_lo, hi_mm = (double)(lut_lo + lut_n);
+      // numpy.linspace(c - 3 sigma, c + 3 sigma, 10) (:221-227) and position_to_index
+      // (:107-118: whole-mm floor, low edge inclusive, high edge exclusive) per mesh line
+      const double xlo = xy.x - 3.0 * sigma, xhi = xy.x + 3.0 * sigma;
+      const double ylo = xy.y - 3.0 * sigma, yhi = xy.y + 3.0 * sigma;
+      const double sx = (xhi - xlo) / (double)(MESH - 1), sy = (yhi - ylo) / (double)(MESH - 1);
 #pragma unroll
-            for (int i = 0; i < MESH; ++i) {
-              const double x = (i == MESH - 1) ? xhi : (double)i * sx + xlo;
-              const double y = (i == MESH - 1) ? yhi : (double)i * sy + ylo;
-              const double fx = floor(x * 1000.0), fy = floor(y * 1000.0);
-              sh.st_ix[slot][i] = (fx >= lo_mm && fx < hi_mm) ? (short)((int)fx - lut_lo) : (short)-1;
-              sh.st_iy[slot][i] = (fy >= lo_mm && fy < hi_mm) ? (short)((int)fy - lut_lo) : (short)-1;
-            }
-            sh.st_n[slot] = tn.y;
-            sh.st_wl[slot] = n_slices == 1 ? 1.0 : a.det.long_weights[sl];
-            sh.st_tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
-          }
-        }
+      for (int i = 0; i < MESH; ++i) {
+        const double x = (i == MESH - 1) ? xhi : (double)i * sx + xlo;
+        const double y = (i == MESH - 1) ? yhi : (double)i * sy + ylo;
+        const double fx = floor(x * 1000.0), fy = floor(y * 1000.0);
+        sh.st_ix[slot][i] = (fx >= lo_mm && fx < hi_mm) ? (short)((int)fx - lut_lo) : (short)-1;
+        sh.st_iy[slot][i] = (fy >= lo_mm && fy < hi_mm) ? (short)((int)fy - lut_lo) : (short)-1;
       }
+      sh.st_n[slot] = tn.y;
+      sh.st_wl[slot] = n_slices == 1 ? 1.0 : a.det.long_weights[sl];
+      sh.st_tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
+    };
+    for (int c0 = 0, chunk = 0; c0 < total_s && !stop; c0 += SC_THREADS, ++chunk) {
+      bool in_win = false;
+      double2 xy = {0.0, 0.0}, tn = {0.0, 0.0};
+      int isim = 0, sl = 0;
+      if (c0 + tid < total_s) {  // the whole record in one round trip, in the window or not
+        const int c = (c0 + tid) / n_slices;
+        sl = (c0 + tid) - c * n_slices;
+        const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
+        xy = reinterpret_cast<const double2*>(rec)[0];
+        tn = reinterpret_cast<const double2*>(rec)[1];
+        const double ts = tn.x >= 0.0 ? slice_time(a.det, tn.x, sl, n_slices) : -1.0;
+        in_win = ts >= 0.0 && ts < (double)ATTPC_NUM_TB && (int)ts >= win_a && (int)ts < win_b;
+      }
+      const unsigned long long bal = __ballot(in_win);
+      if (lane == 0) sh.stage_sum[chunk & 1][tid >> 6] = __popcll(bal);
       __syncthreads();
-      PHASE_MARK(3);
+      // rank among the window's entries; entries outside the window never match a staging slot
+      int rank = in_win ? filled + (int)__popcll(bal & ((1ull << lane) - 1ull)) : -(1 << 30);
+      int filled_new = filled;
+#pragma unroll
+      for (int w = 0; w < N_WAVES; ++w) {
+        const int n_w = sh.stage_sum[chunk & 1][w];
+        rank += w < (tid >> 6) ? n_w : 0;
+        filled_new += n_w;
+      }
+      const bool last_chunk = c0 + SC_THREADS >= total_s;
+      if (rank - round_lo >= 0 && rank - round_lo < STAGE) stage_entry(rank - round_lo, xy, tn, isim, sl);
+      for (;;) {
+        const int pending = filled_new - round_lo;  // staged entries, workgroup uniform
+        if (pending < STAGE && !(last_chunk && pending > 0)) break;  // keep filling / nothing left
+        const int n_stage = min(pending, STAGE);
+        __syncthreads();
+        PHASE_MARK(3);
+        PHASE_COUNT(12, 1);                                          // rows rounds
+        PHASE_COUNT(13, n_stage);                                    // staged entries
+        PHASE_COUNT(14, (n_stage * MESH + SC_THREADS - 1) / SC_THREADS);  // 64-row passes of the busiest wave
 
-      // rows -> runs -> this wave's queue -> table, 64 mesh rows per wave at a time.  The row
-      // code is written branch-free (selects, clamped addresses, a dump slot for disabled queue
-      // writes): divergent `if`s cost more exec-mask bookkeeping than the work they skip.
-      bool ok = true;
-      {
-        const int n_rows = sh.n_stage * MESH;
-        const int wave = tid >> 6;
-        uint32_t* __restrict__ q_key = sh.queue[wave][0];
-        uint32_t* __restrict__ q_chg = sh.queue[wave][1];
-        for (int row0 = wave * 64; row0 < n_rows; row0 += SC_THREADS) {  // wave-uniform trip count
-          const int row = min(row0 + lane, n_rows - 1);
-          const bool have = row0 + lane < n_rows;
-          const int st = row / MESH;
-          const int i = row - st * MESH;
-          const int tbw = sh.st_tb[st];
-          const bool point = (tbw & (1 << 30)) != 0;
-          const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
-          const double n_el = sh.st_n[st];
-          const double wl = sh.st_wl[st];
-          const int ix = sh.st_ix[st][i];
-          // point_transport (transporter.py:123-169): all electrons straight down.  With
-          // sigma == 0 every mesh line sits on the centre: row 0, pixel 0 stand for the sample.
-          const bool live = have && ix >= 0 && (!point || i == 0);
-          const int16_t* __restrict__ lut_row = lut + max(ix, 0) * lut_n;
-          int raw[MESH];
-#pragma unroll
-          for (int j = 0; j < MESH; ++j) {  // 10 independent gathers in flight (clamped address)
-            const int iy = sh.st_iy[st][j];
-            const int pad = (int)lut_row[max(iy, 0)];
-            raw[j] = (live && iy >= 0 && (!point || j == 0)) ? pad : -1;
-          }
-#ifdef ATTPC_PHASE_TIMERS
-          asm volatile("" ::"v"(raw[0]), "v"(raw[9]));
-          PHASE_SYNC;
-          PHASE_MARK(8);
-#endif
-          // truncate per pixel (transporter.py:240-246), merge runs of equal pads: a run's
-          // total sits with its last pixel
-          double run_q[MESH];
-          uint32_t ends = 0;  // bit j: pixel j ends a run on a real pad
-          bool big = false;   // a run does not fit the queue's u32 charge (never for real gains)
-          {
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < MESH; ++j) {
-              const double w = point ? 1.0 : sh.wtab[i * MESH + j];
-              const double t = trunc((w * wl) * n_el);  // wl == 1 exactly without the extension
-              acc += raw[j] >= 0 ? t : 0.0;
-              const bool last = (j == MESH - 1) || (raw[j < MESH - 1 ? j + 1 : j] != raw[j]);
-              run_q[j] = acc;
-              ends |= (last && raw[j] >= 0) ? (1u << j) : 0u;
-              big = big || (last && acc >= 4294967296.0);
-              acc = last ? 0.0 : acc;
+        // rows -> runs -> this wave's queue -> table, 64 mesh rows per wave at a time.  The row
+        // code is written branch-free (selects, clamped addresses, a dump slot for disabled queue
+        // writes): divergent `if`s cost more exec-mask bookkeeping than the work they skip.
+        bool ok = true;
+        {
+          const int n_rows = n_stage * MESH;
+          const int wave = tid >> 6;
+          uint32_t* __restrict__ q_key = sh.queue[wave][0];
+          uint32_t* __restrict__ q_chg = sh.queue[wave][1];
+          for (int row0 = wave * 64; row0 < n_rows; row0 += SC_THREADS) {  // wave-uniform trip count
+            const int row = min(row0 + lane, n_rows - 1);
+            const bool have = row0 + lane < n_rows;
+            const int st = row / MESH;
+            const int i = row - st * MESH;
+            const int tbw = sh.st_tb[st];
+            const bool point = (tbw & (1 << 30)) != 0;
+            const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
+            const double n_el = sh.st_n[st];
+            const double wl = sh.st_wl[st];
+            const int ix = sh.st_ix[st][i];
+            // point_transport (transporter.py:123-169): all electrons straight down.  With
+            // sigma == 0 every mesh line sits on the centre: row 0, pixel 0 stand for the sample.
+            const bool live = have && ix >= 0 && (!point || i == 0);
+            const int16_t* __restrict__ lut_col = lut + max(ix, 0);  // transposed LUT: [iy][ix]
+            int raw[MESH];
+  #pragma unroll
+            for (int j = 0; j < MESH; ++j) {  // 10 independent gathers in flight (clamped address)
+              const int iy = sh.st_iy[st][j];
+              const int pad = (int)lut_col[max(iy, 0) * lut_n];
+              raw[j] = (live && iy >= 0 && (!point || j == 0)) ? pad : -1;
             }
-          }
-          if (__any(big)) {  // rare: such rows go pixel by pixel straight into the table
-            if (big) {
-              ends = 0;
-#pragma unroll 1
-              for (int j = 0; j < MESH && ok; ++j) {
-                const int iy = sh.st_iy[st][j];
-                const int pad = (live && iy >= 0 && (!point || j == 0)) ? (int)lut_row[max(iy, 0)] : -1;
-                if (pad >= 0) ok = table_add(sh, word_hi | (uint32_t)pad, (unsigned long long)(((point ? 1.0 : sh.wtab[i * MESH + j]) * wl) * n_el));
+  #ifdef ATTPC_PHASE_TIMERS
+            asm volatile("" ::"v"(raw[0]), "v"(raw[9]));
+            PHASE_SYNC;
+            PHASE_MARK(8);
+  #endif
+            // truncate per pixel (transporter.py:240-246), merge runs of equal pads: a run's
+            // total sits with its last pixel
+            double run_q[MESH];
+            uint32_t ends = 0;  // bit j: pixel j ends a run on a real pad
+            bool big = false;   // a run does not fit the queue's u32 charge (never for real gains)
+            {
+              double acc = 0.0;
+  #pragma unroll
+              for (int j = 0; j < MESH; ++j) {
+                const double w = point ? 1.0 : sh.wtab[i * MESH + j];
+                const double t = trunc((w * wl) * n_el);  // wl == 1 exactly without the extension
+                acc += raw[j] >= 0 ? t : 0.0;
+                const bool last = (j == MESH - 1) || (raw[j < MESH - 1 ? j + 1 : j] != raw[j]);
+                run_q[j] = acc;
+                ends |= (last && raw[j] >= 0) ? (1u << j) : 0u;
+                big = big || (last && acc >= 4294967296.0);
+                acc = last ? 0.0 : acc;
               }
             }
-          }
-#ifdef ATTPC_PHASE_TIMERS
-          asm volatile("" ::"v"(ends), "v"(run_q[9]));
-          PHASE_SYNC;
-          PHASE_MARK(9);
-#endif
-          const int n_runs = __popc(ends);
-          int incl = n_runs;  // wave prefix sum -> queue positions
-          for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(incl, off);
-            incl += lane >= off ? up : 0;
-          }
-          const int wave_total = __shfl(incl, 63);
-          const int first = incl - n_runs;
-          for (int pass0 = 0; pass0 < wave_total; pass0 += WAVE_QUEUE) {
-            int e = first - pass0;  // queue position of this lane's next run in this pass
-#pragma unroll
-            for (int j = 0; j < MESH; ++j) {
-              const bool put = ((ends >> j) & 1u) && e >= 0 && e < WAVE_QUEUE;
-              const int at = put ? e : WAVE_QUEUE;  // WAVE_QUEUE = dump slot
-              q_key[at] = word_hi | (uint32_t)raw[j];
-              q_chg[at] = (uint32_t)run_q[j];
-              e += (int)((ends >> j) & 1u);
+            if (__any(big)) {  // rare: such rows go pixel by pixel straight into the table
+              if (big) {
+                ends = 0;
+  #pragma unroll 1
+                for (int j = 0; j < MESH && ok; ++j) {
+                  const int iy = sh.st_iy[st][j];
+                  const int pad = (live && iy >= 0 && (!point || j == 0)) ? (int)lut_col[max(iy, 0) * lut_n] : -1;
+                  if (pad >= 0) ok = table_add(sh, word_hi | (uint32_t)pad, (unsigned long long)(((point ? 1.0 : sh.wtab[i * MESH + j]) * wl) * n_el));
+                }
+              }
             }
-            const int n_q = min(wave_total - pass0, WAVE_QUEUE);
-#ifdef ATTPC_PHASE_TIMERS
+  #ifdef ATTPC_PHASE_TIMERS
+            asm volatile("" ::"v"(ends), "v"(run_q[9]));
             PHASE_SYNC;
-            PHASE_MARK(10);
-#endif
-            for (int k = lane; k < n_q && ok; k += 64) ok = table_add(sh, q_key[k], (unsigned long long)q_chg[k]);
-#ifdef ATTPC_PHASE_TIMERS
-            PHASE_SYNC;
-            PHASE_MARK(11);
-#endif
+            PHASE_MARK(9);
+  #endif
+            const int n_runs = __popc(ends);
+            int incl = n_runs;  // wave prefix sum -> queue positions
+            for (int off = 1; off < 64; off <<= 1) {
+              const int up = __shfl_up(incl, off);
+              incl += lane >= off ? up : 0;
+            }
+            const int wave_total = __shfl(incl, 63);
+            const int first = incl - n_runs;
+            for (int pass0 = 0; pass0 < wave_total; pass0 += WAVE_QUEUE) {
+              int e = first - pass0;  // queue position of this lane's next run in this pass
+  #pragma unroll
+              for (int j = 0; j < MESH; ++j) {
+                const bool put = ((ends >> j) & 1u) && e >= 0 && e < WAVE_QUEUE;
+                const int at = put ? e : WAVE_QUEUE;  // WAVE_QUEUE = dump slot
+                q_key[at] = word_hi | (uint32_t)raw[j];
+                q_chg[at] = (uint32_t)run_q[j];
+                e += (int)((ends >> j) & 1u);
+              }
+              const int n_q = min(wave_total - pass0, WAVE_QUEUE);
+  #ifdef ATTPC_PHASE_TIMERS
+              PHASE_SYNC;
+              PHASE_MARK(10);
+  #endif
+              for (int k = lane; k < n_q && ok; k += 64) ok = table_add(sh, q_key[k], (unsigned long long)q_chg[k]);
+  #ifdef ATTPC_PHASE_TIMERS
+              PHASE_SYNC;
+              PHASE_MARK(11);
+  #endif
+            }
+            if (__any(!ok)) break;  // table too full: the whole wave stops together (shuffles above)
           }
-          if (__any(!ok)) break;  // table too full: the whole wave stops together (shuffles above)
+        }
+        if (!ok) sh.overflow = 1;
+        __syncthreads();
+        PHASE_MARK(4);
+        if (sh.overflow) {  // uniform: every thread sees the flag after the barrier
+          stop = true;
+          break;
+        }
+        round_lo += n_stage;
+        if (filled_new <= round_lo) break;
+        if (rank - round_lo >= 0 && rank - round_lo < STAGE) {  // rest of this chunk: the records were not
+          const int c = (c0 + tid) / n_slices;                   // kept in registers across the rows phase
+          int isim2;
+          const double* rec = sample_ptr(sh, arena, n_sim, c, isim2);
+          stage_entry(rank - round_lo, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1],
+                      isim2, (c0 + tid) - c * n_slices);
         }
       }
-      if (!ok) sh.overflow = 1;
-      __syncthreads();
-      PHASE_MARK(4);
-      if (sh.overflow) break;  // uniform: every thread sees the flag after the barrier
+      filled = filled_new;
     }
 
     if (sh.overflow) {
@@ -489,9 +556,14 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
     unsigned long long g_base = 0ull, g_seg = 0ull;
     if (tid == 0) {
       sh.wg_cursor = 0u;
-      if (n_rows) {  // two independent global atomics in flight while the slots are compacted
-        g_base = atomicAdd(&a.out.ctrl[0], (unsigned long long)n_rows);
-        g_seg = atomicAdd(&a.out.ctrl[1], 1ull);
+      if (n_rows) {  // two independent global atomics in flight while the slots are compacted.
+        // The address is made opaque (a VGPR the compiler cannot prove uniform): with a uniform
+        // address LLVM's atomic optimizer rewrites the add into "one lane adds, readfirstlane the
+        // result", and the readfirstlane waits for each atomic's round trip right here.
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        g_base = atomicAdd(&a.out.ctrl[zero], (unsigned long long)n_rows);
+        g_seg = atomicAdd(&a.out.ctrl[zero + 1], 1ull);
       }
     }
     __syncthreads();
@@ -518,10 +590,16 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
         wbase += (unsigned int)__popcll(m);
       }
     }
+    PHASE_MARK(15);  // compaction done (wave 0)
     if (tid == 0) {
       unsigned long long base = 0ull;
       if (n_rows) {
         base = g_base;
+#ifdef ATTPC_PHASE_TIMERS
+        asm volatile("" ::"v"(g_base), "v"(g_seg));
+        PHASE_SYNC;
+        PHASE_MARK(16);  // global atomics returned
+#endif
         if (base + n_rows > (unsigned long long)a.out.capacity || g_seg >= (unsigned long long)a.out.seg_capacity) {
           a.out.ctrl[6] = 1ull;  // out of capacity: host re-runs the chunk with larger buffers
           base = ~0ull;
@@ -539,7 +617,9 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
       const int ratio_x16 = sh.win_samples > 0 ? (int)(n_rows * 16u) / sh.win_samples : 16;
       sh.budget = ratio_x16 > 0 ? TARGET_KEYS * 16 / ratio_x16 : TARGET_KEYS;
       sh.budget = min(max(sh.budget, TARGET_KEYS / 8), TARGET_KEYS * 4);
+      PHASE_MARK(17);  // segment written
       select_window(sh, win_b);  // the next window, published by the barrier after the row stores
+      PHASE_MARK(18);
     }
     __syncthreads();
     PHASE_MARK(6);
@@ -562,10 +642,13 @@ __global__ __launch_bounds__(SC_THREADS) void scatter_kernel(ScatterArgs a) {
         o[0] = (double)pad;
         o[1] = (double)tb + ua;
         o[2] = (double)q;
-        a.out.labels[row] = (int64_t)a.layout.indices[word >> 24];
+        a.out.labels[row] = (int64_t)sh.label_of[word >> 24];  // from LDS: a global load here would
+                                                                // make every store wait (one vmcnt)
       }
     }
-    __syncthreads();
+    // no barrier here: the next window was published before the row stores, and the first barrier of
+    // its staging orders these LDS resets before any new insert while the sample loads of that
+    // staging overlap the store acknowledgements
     PHASE_MARK(7);
   }
   PHASE_FLUSH;

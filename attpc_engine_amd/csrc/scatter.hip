@@ -116,11 +116,11 @@ static_assert(STAGE <= SC_THREADS, "one lane per staged sample");
 static_assert(2 * N_WAVES * (WAVE_QUEUE + 2) >= HASH_CAP, "the wave queues double as the slot list of a flush");
 
 struct __align__(16) ScatterShared {
+  double wtab[PIXELS];        // first member: rows of 10 weights are read as five 16-byte pairs
   unsigned long long chg[HASH_CAP];  // electrons per key (ds_add_u64)
   uint32_t keys[HASH_CAP];    // bits 0..13 pad, 14..23 time bucket, 24..26 position in `indices`
-  uint32_t queue[N_WAVES][2][WAVE_QUEUE + 2];  // per wave: [0][k] = key|label, [1][k] = charge (+ dump slot);
-                                               // the whole array is the slot list during a flush
-  double wtab[PIXELS];
+  uint2 queue[N_WAVES][WAVE_QUEUE + 2];  // per wave: (key|label, charge) of queued runs (+ dump slot);
+                                         // the whole array is the slot list during a flush
   double st_n[STAGE];
   double st_wl[STAGE];        // longitudinal slice weight (1 without the extension)
   short st_ix[STAGE][MESH];   // LUT row index of mesh line i, -1 = off the pad plane
@@ -132,8 +132,9 @@ struct __align__(16) ScatterShared {
   unsigned long long cum[ATTPC_NUM_TB];  // inclusive prefix sums per time bucket: low word estimated keys,
                                          // high word staged entries (samples x slices)
   unsigned long long wave_sum[SC_THREADS / 64];
+  unsigned short perm[SC_THREADS];  // entries (sample x slice) sorted by time bucket, events of <= SC_THREADS entries
   int stage_sum[2][SC_THREADS / 64];  // in-window entries per wave of a staging chunk (double buffered)
-  int win_a, win_b, win_samples, budget, overflow, done, failed, retried;
+  int win_a, win_b, win_samples, win_r0, win_n, budget, overflow, done, failed, retried;
   unsigned int wg_cursor, n_keys;
   unsigned long long base;
   unsigned long long charge_sum, key_sum;
@@ -218,6 +219,48 @@ __device__ __forceinline__ bool table_add(ScatterShared& sh, uint32_t want, unsi
   return true;
 }
 
+// The same operation for a whole wave, one queued run per lane (`pending` lanes only), written as
+// one wave-uniform loop with selects instead of per-lane control flow: every trip is a bucket read,
+// at most one compare-and-swap, and the two fire-and-forget updates.  `claimed` counts the new
+// keys of the wave (scalar).  False if some lane ran out of probes.
+__device__ __forceinline__ bool wave_insert(ScatterShared& sh, uint32_t want, uint32_t q, bool pending,
+                                            unsigned int& claimed) {
+  const uint32_t key = want & KEY_MASK;
+  uint32_t b = hash_bucket(key);
+  int probes = 0;
+  bool fail = false;
+  while (__any(pending)) {
+    const uint4 k4 = *reinterpret_cast<const uint4*>(&sh.keys[b * BUCKET]);
+    const bool m0 = (k4.x & KEY_MASK) == key, m1 = (k4.y & KEY_MASK) == key;
+    const bool m2 = (k4.z & KEY_MASK) == key, m3 = (k4.w & KEY_MASK) == key;
+    const bool e0 = k4.x == EMPTY, e1 = k4.y == EMPTY, e2 = k4.z == EMPTY, e3 = k4.w == EMPTY;
+    const bool any_m = m0 || m1 || m2 || m3, any_e = e0 || e1 || e2 || e3;
+    const uint32_t pos_m = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : 3u));
+    const uint32_t pos_e = e0 ? 0u : (e1 ? 1u : (e2 ? 2u : 3u));
+    const uint32_t h = b * BUCKET + (any_m ? pos_m : pos_e);
+    uint32_t cur = m0 ? k4.x : (m1 ? k4.y : (m2 ? k4.z : k4.w));
+    const bool try_claim = pending && !any_m && any_e;
+    uint32_t old = 0u;
+    if (try_claim) old = atomicCAS(&sh.keys[h], EMPTY, want);
+    const bool won = try_claim && old == EMPTY;
+    const bool same = try_claim && (old & KEY_MASK) == key;  // another lane claimed it for this key
+    cur = won ? want : (same ? old : cur);
+    const bool done = pending && (any_m || won || same);
+    if (done) {
+      if (cur < want) atomicMax(&sh.keys[h], want);
+      atomicAdd(&sh.chg[h], (unsigned long long)q);
+    }
+    claimed += (unsigned int)__popcll(__ballot(won));
+    const bool advance = pending && !any_m && !any_e;  // full bucket of other keys
+    probes += advance ? 1 : 0;
+    const bool give_up = advance && probes >= MAX_BUCKET_PROBES;
+    fail = fail || give_up;
+    b = advance ? ((b + 1) & (N_BUCKETS - 1)) : b;
+    pending = pending && !done && !give_up;  // a lost compare-and-swap looks at the same bucket again
+  }
+  return !__any(fail);
+}
+
 // Next window [win_a, win_b) of time buckets: starts at the first non-empty bucket >= `from` and
 // extends while the estimated key count stays within the budget (at least one bucket).  A window
 // that does not reach the end of the event is then cut back to a whole number of row passes: the
@@ -242,6 +285,8 @@ __device__ __forceinline__ void select_window(ScatterShared& sh, int from) {
   sh.win_a = a0;
   sh.win_b = b0;
   sh.win_samples = (int)((unsigned int)sh.cum[b0 - 1] - keys0);
+  sh.win_r0 = (int)entries0;  // the buckets between `from` and a0 are empty
+  sh.win_n = (int)((unsigned int)(sh.cum[b0 - 1] >> 32) - entries0);
 }
 
 __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_kernel(ScatterArgs a) {
@@ -263,7 +308,10 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
     const double di = (double)(p / MESH) - 4.5, dj = (double)(p % MESH) - 4.5;
     sh.wtab[p] = (36.0 / 81.0) / TWO_PI * exp(-(2.0 / 9.0) * (di * di + dj * dj));
   }
-  for (int i = tid; i < ATTPC_NUM_TB; i += SC_THREADS) sh.cum[i] = 0ull;
+  for (int i = tid; i < ATTPC_NUM_TB; i += SC_THREADS) {
+    sh.cum[i] = 0ull;
+    reinterpret_cast<uint32_t*>(&sh.st_ix[0][0])[i] = 0u;  // per-bucket cursors of the entry sort
+  }
   if (tid < ATTPC_MAX_SIM) sh.label_of[tid] = (long long)a.layout.indices[tid];
   if (tid == 0) {
     int acc = 0;
@@ -288,16 +336,34 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
 
   // ---- histogram of kept samples per time bucket (all nuclei), then its prefix sum ----
   const int n_slices = a.det.longitudinal_diffusion > 0.0 ? ATTPC_LONG_STEPS : 1;
-  for (int c = tid; c < total; c += SC_THREADS) {
-    int isim;
-    const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
-    // t < 0 (sigma_t would be NaN: undefined in the reference) and tb >= 512 (removed by the
-    // 0 <= tb < 512 mask of simulator.py:111-113) never reach the output
-    if (!(t >= 0.0)) continue;
-    const int est = key_estimate((int)fmin(t, 511.0), spread);
-    for (int sl = 0; sl < n_slices; ++sl) {
-      const double ts = slice_time(a.det, t, sl, n_slices);
-      if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)ts], (1ull << 32) | (unsigned long long)est);
+  const int total_s = total * n_slices;  // entries = samples x slices
+  // t < 0 (sigma_t would be NaN: undefined in the reference) and tb >= 512 (removed by the
+  // 0 <= tb < 512 mask of simulator.py:111-113) never reach the output
+  const bool sorted = total_s <= SC_THREADS;  // one thread per entry: sort them by time bucket once
+  int my_tb = -1;
+  if (sorted) {
+    if (tid < total_s) {
+      const int c = tid / n_slices;
+      int isim;
+      const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
+      if (t >= 0.0) {
+        const double ts = slice_time(a.det, t, tid - c * n_slices, n_slices);
+        if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
+          my_tb = (int)ts;
+          atomicAdd(&sh.cum[my_tb], (1ull << 32) | (unsigned long long)key_estimate((int)fmin(t, 511.0), spread));
+        }
+      }
+    }
+  } else {
+    for (int c = tid; c < total; c += SC_THREADS) {
+      int isim;
+      const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
+      if (!(t >= 0.0)) continue;
+      const int est = key_estimate((int)fmin(t, 511.0), spread);
+      for (int sl = 0; sl < n_slices; ++sl) {
+        const double ts = slice_time(a.det, t, sl, n_slices);
+        if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)ts], (1ull << 32) | (unsigned long long)est);
+      }
     }
   }
   __syncthreads();
@@ -327,6 +393,10 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
   }
   __syncthreads();
 
+  if (my_tb >= 0) {  // counting sort: a window is then a contiguous range of perm[]
+    const unsigned int before = my_tb > 0 ? (unsigned int)(sh.cum[my_tb - 1] >> 32) : 0u;
+    sh.perm[before + atomicAdd(&reinterpret_cast<uint32_t*>(&sh.st_ix[0][0])[my_tb], 1u)] = (unsigned short)tid;
+  }
   if (tid == 0) select_window(sh, 0);
   __syncthreads();
   unsigned long long my_charge = 0ull, my_keys = 0ull;
@@ -342,10 +412,150 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
     // The (sample, slice) list is scanned in chunks of one entry per thread; the entries inside
     // the window are ranked (ballot prefix + wave totals) and staged densely, so a rows round runs
     // on a full staging buffer (or on the window's remainder) whatever the order of the samples.
-    const int total_s = total * n_slices;
     int round_lo = 0;  // rank of staging slot 0
     int filled = 0;    // in-window entries of the chunks before this one
     bool stop = false;
+    // One rows round over the staged entries.  Returns false when the table is too full.
+    auto rows_round = [&](int n_stage) -> bool {
+      const int n_rows = n_stage * MESH;
+      const int wave = tid >> 6;
+      uint2* __restrict__ queue = sh.queue[wave];
+      const char* __restrict__ lut_bytes = reinterpret_cast<const char*>(lut);
+      const unsigned int row_pitch = 2u * (unsigned int)lut_n;  // bytes per iy row of the transposed LUT
+      unsigned int claimed = 0u;  // new keys of this wave (wave uniform)
+      bool ok = true;
+      for (int row0 = wave * 64; row0 < n_rows; row0 += SC_THREADS) {  // wave-uniform trip count
+        const int row = min(row0 + lane, n_rows - 1);
+        const bool have = row0 + lane < n_rows;
+        const int st = row / MESH;
+        const int i = row - st * MESH;
+        const int tbw = sh.st_tb[st];
+        const bool point = (tbw & (1 << 30)) != 0;
+        const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
+        const double n_el = sh.st_n[st];
+        const double wl = sh.st_wl[st];  // 1 without the longitudinal extension
+        const int ix = sh.st_ix[st][i];
+        // the row's 10 iy indices (5 dwords) and weights (5 x 16 bytes)
+        const uint32_t* __restrict__ iy32 = reinterpret_cast<const uint32_t*>(&sh.st_iy[st][0]);
+        const double2* __restrict__ w2 = reinterpret_cast<const double2*>(&sh.wtab[i * MESH]);
+        int iy[MESH];
+        double w[MESH];
+#pragma unroll
+        for (int j = 0; j < MESH; j += 2) {
+          const uint32_t pair = iy32[j >> 1];
+          iy[j] = (int)(short)(pair & 0xffffu);
+          iy[j + 1] = (int)(short)(pair >> 16);
+          const double2 ww = w2[j >> 1];
+          w[j] = ww.x;
+          w[j + 1] = ww.y;
+        }
+        unsigned int valid = 0u;  // bit j: pixel j is on the LUT
+        int pad[MESH];
+        {
+          // 10 independent gathers in flight (clamped addresses, 32-bit byte offsets from the uniform
+          // base).  The empty asm takes all ten results: without it the compiler sinks each load into
+          // a branch on its select condition and waits there -- ten serial L2 round trips.
+          const unsigned int col = 2u * (unsigned int)max(ix, 0);
+#pragma unroll
+          for (int j = 0; j < MESH; ++j) {
+            const unsigned int off = __umul24((unsigned int)max(iy[j], 0), row_pitch) + col;
+            pad[j] = (int)*reinterpret_cast<const int16_t*>(lut_bytes + off);
+            valid |= iy[j] >= 0 ? (1u << j) : 0u;
+          }
+          asm volatile("" : "+v"(pad[0]), "+v"(pad[1]), "+v"(pad[2]), "+v"(pad[3]), "+v"(pad[4]), "+v"(pad[5]),
+                       "+v"(pad[6]), "+v"(pad[7]), "+v"(pad[8]), "+v"(pad[9]));
+        }
+#ifdef ATTPC_PHASE_TIMERS
+        PHASE_SYNC;
+        PHASE_MARK(8);
+#endif
+        // per-pixel electrons int(pdf h^2 n) (transporter.py:240-246) as u32; the centre pixel is the
+        // largest of the row, so one check bounds every run total of the row below 2^32
+        uint32_t el[MESH];
+#pragma unroll
+        for (int j = 0; j < MESH; ++j) el[j] = (uint32_t)((w[j] * wl) * n_el);  // cvt truncates
+        const bool big = el[MESH / 2] >= (1u << 28);
+        const bool on_plane = have && ix >= 0;
+        // point_transport (transporter.py:123-169, sigma == 0: all electrons straight down, row 0 /
+        // pixel 0 stand for the sample) and rows too large for u32 go pixel by pixel into the table
+        const bool slow = on_plane && (point || big);
+        bool slow_ok = true;
+        if (__any(slow)) {
+          if (slow) {
+#pragma unroll 1
+            for (int j = 0; j < MESH && slow_ok; ++j) {
+              if (!((valid >> j) & 1u) || (point && (i != 0 || j != 0))) continue;
+              const unsigned int off = __umul24((unsigned int)iy[j], row_pitch) + 2u * (unsigned int)ix;
+              const int p = (int)*reinterpret_cast<const int16_t*>(lut_bytes + off);
+              const double q = ((point ? 1.0 : sh.wtab[i * MESH + j]) * wl) * n_el;
+              if (p >= 0) slow_ok = table_add(sh, word_hi | (uint32_t)p, (unsigned long long)q);
+            }
+          }
+        }
+        const bool live = on_plane && !slow;
+        // merge runs of equal pads: a run's total sits with its last pixel
+        uint32_t run_q[MESH];
+        uint32_t ends = 0u;  // bit j: pixel j ends a run on a real pad
+        {
+          uint32_t acc = 0u;
+#pragma unroll
+          for (int j = 0; j < MESH; ++j) {
+            pad[j] = (live && ((valid >> j) & 1u)) ? pad[j] : -1;
+          }
+#pragma unroll
+          for (int j = 0; j < MESH; ++j) {
+            acc += pad[j] >= 0 ? el[j] : 0u;
+            const bool last = (j == MESH - 1) || (pad[j < MESH - 1 ? j + 1 : j] != pad[j]);
+            run_q[j] = acc;
+            ends |= (last && pad[j] >= 0) ? (1u << j) : 0u;
+            acc = last ? 0u : acc;
+          }
+        }
+#ifdef ATTPC_PHASE_TIMERS
+        asm volatile("" ::"v"(ends), "v"(run_q[9]));
+        PHASE_SYNC;
+        PHASE_MARK(9);
+#endif
+        // queue positions: exclusive prefix of the run counts (0..10, four bits) over the wave from
+        // four ballots and mbcnt -- no cross-lane data movement
+        const uint32_t n_runs = (uint32_t)__popc(ends);
+        int first = 0, wave_total = 0;
+#pragma unroll
+        for (int bit = 0; bit < 4; ++bit) {
+          const unsigned long long m = __ballot((n_runs >> bit) & 1u);
+          first += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << bit;
+          wave_total += (int)__popcll(m) << bit;
+        }
+        for (int pass0 = 0; pass0 < wave_total; pass0 += WAVE_QUEUE) {
+          int e = first - pass0;  // queue position of this lane's next run in this pass
+#pragma unroll
+          for (int j = 0; j < MESH; ++j) {
+            const bool put = ((ends >> j) & 1u) && e >= 0 && e < WAVE_QUEUE;
+            queue[put ? e : WAVE_QUEUE] = make_uint2(word_hi | (uint32_t)pad[j], run_q[j]);  // WAVE_QUEUE = dump slot
+            e += (int)((ends >> j) & 1u);
+          }
+          const int n_q = min(wave_total - pass0, WAVE_QUEUE);
+#ifdef ATTPC_PHASE_TIMERS
+          PHASE_SYNC;
+          PHASE_MARK(10);
+#endif
+          for (int k0 = 0; k0 < n_q && ok; k0 += 64) {  // wave uniform
+            const uint2 item = queue[min(k0 + lane, n_q - 1)];
+            ok = wave_insert(sh, item.x, item.y, k0 + lane < n_q, claimed);
+          }
+#ifdef ATTPC_PHASE_TIMERS
+          PHASE_SYNC;
+          PHASE_MARK(11);
+#endif
+          if (!ok) break;
+        }
+        ok = ok && !__any(!slow_ok);  // the slow path fails in single lanes
+        if (!ok) break;    // table too full: the whole wave stops together
+      }
+      if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);  // rows of the window's flush
+      return ok;
+    };
+
     // one (sample, slice) entry -> staging slot: sigma_t and the LUT indices of its 20 mesh lines
     auto stage_entry = [&](int slot, double2 xy, double2 tn, int isim, int sl) {
       const int tb = (int)slice_time(a.det, tn.x, sl, n_slices);  // transporter.py:238
@@ -368,7 +578,31 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
       sh.st_wl[slot] = n_slices == 1 ? 1.0 : a.det.long_weights[sl];
       sh.st_tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
     };
-    for (int c0 = 0, chunk = 0; c0 < total_s && !stop; c0 += SC_THREADS, ++chunk) {
+    if (sorted) {  // the window is perm[win_r0 .. win_r0 + win_n): stage it densely, STAGE entries per round
+      const int r0 = sh.win_r0, n_win = sh.win_n;
+      for (int base = 0; base < n_win; base += STAGE) {
+        const int n_stage = min(STAGE, n_win - base);
+        if (tid < n_stage) {
+          const int cs = (int)sh.perm[r0 + base + tid];
+          const int c = cs / n_slices;
+          int isim;
+          const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
+          stage_entry(tid, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1], isim,
+                      cs - c * n_slices);
+        }
+        __syncthreads();
+        PHASE_MARK(3);
+        PHASE_COUNT(12, 1);
+        PHASE_COUNT(13, n_stage);
+        PHASE_COUNT(14, (n_stage * MESH + SC_THREADS - 1) / SC_THREADS);
+        const bool ok = rows_round(n_stage);
+        if (!ok) sh.overflow = 1;
+        __syncthreads();
+        PHASE_MARK(4);
+        if (sh.overflow) break;  // uniform: every thread sees the flag after the barrier
+      }
+    }
+    for (int c0 = 0, chunk = 0; !sorted && c0 < total_s && !stop; c0 += SC_THREADS, ++chunk) {
       bool in_win = false;
       double2 xy = {0.0, 0.0}, tn = {0.0, 0.0};
       int isim = 0, sl = 0;
@@ -405,109 +639,8 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
         PHASE_COUNT(13, n_stage);                                    // staged entries
         PHASE_COUNT(14, (n_stage * MESH + SC_THREADS - 1) / SC_THREADS);  // 64-row passes of the busiest wave
 
-        // rows -> runs -> this wave's queue -> table, 64 mesh rows per wave at a time.  The row
-        // code is written branch-free (selects, clamped addresses, a dump slot for disabled queue
-        // writes): divergent `if`s cost more exec-mask bookkeeping than the work they skip.
-        bool ok = true;
-        {
-          const int n_rows = n_stage * MESH;
-          const int wave = tid >> 6;
-          uint32_t* __restrict__ q_key = sh.queue[wave][0];
-          uint32_t* __restrict__ q_chg = sh.queue[wave][1];
-          for (int row0 = wave * 64; row0 < n_rows; row0 += SC_THREADS) {  // wave-uniform trip count
-            const int row = min(row0 + lane, n_rows - 1);
-            const bool have = row0 + lane < n_rows;
-            const int st = row / MESH;
-            const int i = row - st * MESH;
-            const int tbw = sh.st_tb[st];
-            const bool point = (tbw & (1 << 30)) != 0;
-            const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
-            const double n_el = sh.st_n[st];
-            const double wl = sh.st_wl[st];
-            const int ix = sh.st_ix[st][i];
-            // point_transport (transporter.py:123-169): all electrons straight down.  With
-            // sigma == 0 every mesh line sits on the centre: row 0, pixel 0 stand for the sample.
-            const bool live = have && ix >= 0 && (!point || i == 0);
-            const int16_t* __restrict__ lut_col = lut + max(ix, 0);  // transposed LUT: [iy][ix]
-            int raw[MESH];
-  #pragma unroll
-            for (int j = 0; j < MESH; ++j) {  // 10 independent gathers in flight (clamped address)
-              const int iy = sh.st_iy[st][j];
-              const int pad = (int)lut_col[max(iy, 0) * lut_n];
-              raw[j] = (live && iy >= 0 && (!point || j == 0)) ? pad : -1;
-            }
-  #ifdef ATTPC_PHASE_TIMERS
-            asm volatile("" ::"v"(raw[0]), "v"(raw[9]));
-            PHASE_SYNC;
-            PHASE_MARK(8);
-  #endif
-            // truncate per pixel (transporter.py:240-246), merge runs of equal pads: a run's
-            // total sits with its last pixel
-            double run_q[MESH];
-            uint32_t ends = 0;  // bit j: pixel j ends a run on a real pad
-            bool big = false;   // a run does not fit the queue's u32 charge (never for real gains)
-            {
-              double acc = 0.0;
-  #pragma unroll
-              for (int j = 0; j < MESH; ++j) {
-                const double w = point ? 1.0 : sh.wtab[i * MESH + j];
-                const double t = trunc((w * wl) * n_el);  // wl == 1 exactly without the extension
-                acc += raw[j] >= 0 ? t : 0.0;
-                const bool last = (j == MESH - 1) || (raw[j < MESH - 1 ? j + 1 : j] != raw[j]);
-                run_q[j] = acc;
-                ends |= (last && raw[j] >= 0) ? (1u << j) : 0u;
-                big = big || (last && acc >= 4294967296.0);
-                acc = last ? 0.0 : acc;
-              }
-            }
-            if (__any(big)) {  // rare: such rows go pixel by pixel straight into the table
-              if (big) {
-                ends = 0;
-  #pragma unroll 1
-                for (int j = 0; j < MESH && ok; ++j) {
-                  const int iy = sh.st_iy[st][j];
-                  const int pad = (live && iy >= 0 && (!point || j == 0)) ? (int)lut_col[max(iy, 0) * lut_n] : -1;
-                  if (pad >= 0) ok = table_add(sh, word_hi | (uint32_t)pad, (unsigned long long)(((point ? 1.0 : sh.wtab[i * MESH + j]) * wl) * n_el));
-                }
-              }
-            }
-  #ifdef ATTPC_PHASE_TIMERS
-            asm volatile("" ::"v"(ends), "v"(run_q[9]));
-            PHASE_SYNC;
-            PHASE_MARK(9);
-  #endif
-            const int n_runs = __popc(ends);
-            int incl = n_runs;  // wave prefix sum -> queue positions
-            for (int off = 1; off < 64; off <<= 1) {
-              const int up = __shfl_up(incl, off);
-              incl += lane >= off ? up : 0;
-            }
-            const int wave_total = __shfl(incl, 63);
-            const int first = incl - n_runs;
-            for (int pass0 = 0; pass0 < wave_total; pass0 += WAVE_QUEUE) {
-              int e = first - pass0;  // queue position of this lane's next run in this pass
-  #pragma unroll
-              for (int j = 0; j < MESH; ++j) {
-                const bool put = ((ends >> j) & 1u) && e >= 0 && e < WAVE_QUEUE;
-                const int at = put ? e : WAVE_QUEUE;  // WAVE_QUEUE = dump slot
-                q_key[at] = word_hi | (uint32_t)raw[j];
-                q_chg[at] = (uint32_t)run_q[j];
-                e += (int)((ends >> j) & 1u);
-              }
-              const int n_q = min(wave_total - pass0, WAVE_QUEUE);
-  #ifdef ATTPC_PHASE_TIMERS
-              PHASE_SYNC;
-              PHASE_MARK(10);
-  #endif
-              for (int k = lane; k < n_q && ok; k += 64) ok = table_add(sh, q_key[k], (unsigned long long)q_chg[k]);
-  #ifdef ATTPC_PHASE_TIMERS
-              PHASE_SYNC;
-              PHASE_MARK(11);
-  #endif
-            }
-            if (__any(!ok)) break;  // table too full: the whole wave stops together (shuffles above)
-          }
-        }
+        // rows -> runs -> this wave's queue -> table, 64 mesh rows per wave at a time
+        const bool ok = rows_round(n_stage);
         if (!ok) sh.overflow = 1;
         __syncthreads();
         PHASE_MARK(4);
@@ -581,7 +714,7 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
       unsigned int wbase = 0;
       if (lane == 0 && cnt) wbase = atomicAdd(&sh.wg_cursor, cnt);
       wbase = __shfl(wbase, 0);
-      uint32_t* __restrict__ list = &sh.queue[0][0][0];
+      uint32_t* __restrict__ list = reinterpret_cast<uint32_t*>(&sh.queue[0][0]);
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         const unsigned long long m = occ_mask[it];
@@ -625,7 +758,7 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
     PHASE_MARK(6);
     const unsigned long long base = sh.base;
     for (unsigned int r = tid; r < n_rows; r += SC_THREADS) {
-      const uint32_t slot = (&sh.queue[0][0][0])[r];
+      const uint32_t slot = reinterpret_cast<const uint32_t*>(&sh.queue[0][0])[r];
       const uint32_t word = sh.keys[slot];
       const unsigned long long q = sh.chg[slot];
       sh.keys[slot] = EMPTY;

@@ -30,6 +30,7 @@ struct DevBuf {
 
 struct attpc_ctx {
   int device = 0;
+  int n_cus = 256;                 // compute units (one scatter workgroup each)
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   std::string error;
@@ -134,8 +135,17 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
   if ((rc = ensure(ctx, ctx->trk_ctrl, 16 * sizeof(uint32_t)))) return rc;
   if ((rc = ensure(ctx, ctx->out_ctrl, 32 * sizeof(unsigned long long)))) return rc;
   size_t want_blocks = std::max<size_t>(ctx->arena_blocks, (size_t)n_tracks * 6 + 1024);
-  int64_t want_rows = std::max<int64_t>(ctx->cloud_capacity, (int64_t)n * 9216 + 65536);
-  int64_t want_segs = std::max<int64_t>(ctx->seg_capacity, (int64_t)n * 6 + 4096);
+  // scatter launch geometry: persistent workgroups, one per compute unit, that take `batch` events per
+  // visit to the event counter and reserve output rows `row_block` at a time (small launches: batch
+  // 1 and exact reservations, so that short runs still spread over the chip and waste no rows)
+  const uint32_t sc_wgs = std::min<uint32_t>((uint32_t)ctx->n_cus, n);
+  const uint32_t sc_batch = std::max<uint32_t>(1u, std::min<uint32_t>(8u, n / (sc_wgs * 8u)));
+  const int64_t est_rows = (int64_t)n * 9216;
+  const uint32_t sc_row_block = est_rows / ((int64_t)sc_wgs * 16) >= 16384
+                                    ? (uint32_t)std::min<int64_t>(est_rows / ((int64_t)sc_wgs * 16), 1 << 18) : 1u;
+  const int64_t hole_rows = sc_row_block > 1u ? (int64_t)sc_wgs * sc_row_block + est_rows / 16 : 0;
+  int64_t want_rows = std::max<int64_t>(ctx->cloud_capacity, est_rows + hole_rows + 65536);
+  int64_t want_segs = std::max<int64_t>(ctx->seg_capacity, (int64_t)n * 6 + 4096 + (int64_t)sc_wgs * 16);
   if (std::getenv("ATTPC_TEST_TINY_BUFFERS") && ctx->arena_blocks == 0) {
     // test hook: start with buffers that are certainly too small so the grow-and-rerun path runs
     want_blocks = 4;
@@ -192,8 +202,10 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
     sa.seed = seed;
     sa.first_event = first_event;
     sa.n_events = n;
+    sa.batch = sc_batch;
+    sa.row_block = sc_row_block;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    launch_scatter_kernel(n, ctx->stream, sa);
+    launch_scatter_kernel(sc_wgs, ctx->stream, sa);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 
@@ -223,12 +235,12 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
             octrl[8], octrl[9], octrl[10], octrl[11], octrl[12], octrl[13], octrl[14], octrl[15], n);
     fprintf(stderr, "[attpc rows-phase cycles] gathers %llu runs %llu scan+queue %llu drain %llu\n", octrl[16], octrl[17], octrl[18], octrl[19]);
     fprintf(stderr, "[attpc rounds] rows-rounds %llu staged %llu busiest-wave passes %llu\n", octrl[20], octrl[21], octrl[22]);
-    fprintf(stderr, "[attpc flush cycles] to-compacted %llu atomics-wait %llu segment %llu select %llu barrier %llu\n", octrl[23], octrl[24], octrl[25], octrl[26], octrl[14]);
+    fprintf(stderr, "[attpc flush cycles] to-barrier %llu to-compacted %llu atomics-wait %llu segment %llu select %llu barrier %llu\n", octrl[27], octrl[23], octrl[24], octrl[25], octrl[26], octrl[14]);
     fprintf(stderr, "[attpc ctrl] rows %llu segments %llu failed %llu retried %llu samples %llu\n", octrl[0], octrl[1],
             octrl[4], octrl[5], octrl[7]);
 #endif
     if (!retry) {
-      res->rows = octrl[0];
+      res->rows = octrl[30];  // rows written; octrl[0] is the reservation cursor (holes included)
       res->segs = octrl[1];
       res->charge = octrl[2];
       res->keys = octrl[3];
@@ -389,6 +401,10 @@ int32_t attpc_ctx_create(int32_t device, attpc_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return ATTPC_E_HIP;
   attpc_ctx* ctx = new attpc_ctx();
   ctx->device = device;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
+  }
   if (hipStreamCreate(&ctx->stream) != hipSuccess) {
     delete ctx;
     return ATTPC_E_HIP;

@@ -84,6 +84,9 @@ constexpr int HASH_CAP = 1 << HASH_BITS;    // slots
 constexpr int WAVE_QUEUE = ATTPC_SC_WAVE_QUEUE;  // queued runs per wave and pass (typ. ~190 per 64 mesh rows)
 constexpr int N_WAVES = SC_THREADS / 64;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr int SEG_BLOCK = 16;            // segment slots reserved at a time
+constexpr int CTRL_NEXT_EVENT = 28;      // out.ctrl[]: next unassigned event of the launch
+constexpr int CTRL_ROWS = 30;            // out.ctrl[]: rows actually written ([0] is the reservation cursor)
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;
 #ifndef ATTPC_SC_TARGET_PCT
 #define ATTPC_SC_TARGET_PCT 50
@@ -134,9 +137,11 @@ struct __align__(16) ScatterShared {
   unsigned long long wave_sum[SC_THREADS / 64];
   unsigned short perm[SC_THREADS];  // entries (sample x slice) sorted by time bucket, events of <= SC_THREADS entries
   int stage_sum[2][SC_THREADS / 64];  // in-window entries per wave of a staging chunk (double buffered)
-  int win_a, win_b, win_samples, win_r0, win_n, budget, overflow, done, failed, retried;
-  unsigned int wg_cursor, n_keys;
+  int win_a, win_b, win_samples, win_r0, win_n, budget, overflow, done, ev_failed, failed, retried;
+  unsigned int wg_cursor, n_keys, batch_first;
   unsigned long long base;
+  unsigned long long row_cur, row_end, seg_cur, seg_end;  // this workgroup's reserved output rows / segment slots
+  unsigned long long wg_samples, wg_rows;                 // workgroup totals (thread 0)
   unsigned long long charge_sum, key_sum;
 };
 
@@ -289,504 +294,548 @@ __device__ __forceinline__ void select_window(ScatterShared& sh, int from) {
   sh.win_n = (int)((unsigned int)(sh.cum[b0 - 1] >> 32) - entries0);
 }
 
+__device__ __forceinline__ int fresh_tid() {
+  int t = (int)threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_kernel(ScatterArgs a) {
   __shared__ ScatterShared sh;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const uint32_t e_local = blockIdx.x;
-  const uint64_t event = a.first_event + e_local;
+  // tid / lane are re-read through an opaque asm at every use (macros below): otherwise the compiler
+  // hoists every tid-derived LDS address of every phase to the top of the kernel, runs out of the 128
+  // VGPRs a 1024-thread workgroup allows and reloads them from scratch memory (a global round trip
+  // each) inside the per-window code
+#define tid (attpc::fresh_tid())
+#define lane (attpc::fresh_tid() & 63)
   const int n_sim = a.layout.n_sim;
-  const uint32_t track0 = e_local * (uint32_t)n_sim;
   const int lut_n = a.det.lut_n, lut_lo = a.det.lut_lo;
   const int16_t* __restrict__ lut = a.det.pad_lut;
   const double* __restrict__ arena = a.trk.arena;
   const float spread = (float)((6.0 / 4.9e-3) * (6.0 / 4.9e-3) * 2.0 * a.det.diffusion * a.det.dv / a.det.efield);
+  const int n_slices = a.det.longitudinal_diffusion > 0.0 ? ATTPC_LONG_STEPS : 1;
 
   PHASE_DECL;
-  // ---- init ----
+  // ---- once per workgroup (persistent: it takes batches of events from a global counter) ----
   for (int p = tid; p < PIXELS; p += SC_THREADS) {
     const double di = (double)(p / MESH) - 4.5, dj = (double)(p % MESH) - 4.5;
     sh.wtab[p] = (36.0 / 81.0) / TWO_PI * exp(-(2.0 / 9.0) * (di * di + dj * dj));
   }
-  for (int i = tid; i < ATTPC_NUM_TB; i += SC_THREADS) {
-    sh.cum[i] = 0ull;
-    reinterpret_cast<uint32_t*>(&sh.st_ix[0][0])[i] = 0u;  // per-bucket cursors of the entry sort
-  }
   if (tid < ATTPC_MAX_SIM) sh.label_of[tid] = (long long)a.layout.indices[tid];
   if (tid == 0) {
-    int acc = 0;
-    for (int k = 0; k < n_sim; ++k) {
-      sh.cnt[k] = acc;
-      acc += a.trk.counts[track0 + k];
-    }
-    for (int k = n_sim; k <= ATTPC_MAX_SIM; ++k) sh.cnt[k] = acc;
-    sh.win_a = 0; sh.win_b = 0; sh.budget = TARGET_KEYS; sh.overflow = 0; sh.done = 0;
     sh.failed = 0; sh.retried = 0; sh.charge_sum = 0ull; sh.key_sum = 0ull; sh.n_keys = 0u;
+    sh.row_cur = 0ull; sh.row_end = 0ull; sh.seg_cur = 0ull; sh.seg_end = 0ull; sh.wg_samples = 0ull; sh.wg_rows = 0ull;
   }
-  clear_table(sh);
-  __syncthreads();
-  const int total = sh.cnt[ATTPC_MAX_SIM];
-  for (int i = tid; i < n_sim * MAX_BLOCKS_PER_TRACK; i += SC_THREADS) {
-    const int k = i / MAX_BLOCKS_PER_TRACK, b = i - k * MAX_BLOCKS_PER_TRACK;
-    const int n_blk = (sh.cnt[k + 1] - sh.cnt[k] + ARENA_BLK - 1) / ARENA_BLK;
-    sh.blocks[k][b] = b < n_blk ? a.trk.block_table[(size_t)(track0 + k) * MAX_BLOCKS_PER_TRACK + b] : 0;
-  }
-  __syncthreads();
-  PHASE_MARK(0);
-
-  // ---- histogram of kept samples per time bucket (all nuclei), then its prefix sum ----
-  const int n_slices = a.det.longitudinal_diffusion > 0.0 ? ATTPC_LONG_STEPS : 1;
-  const int total_s = total * n_slices;  // entries = samples x slices
-  // t < 0 (sigma_t would be NaN: undefined in the reference) and tb >= 512 (removed by the
-  // 0 <= tb < 512 mask of simulator.py:111-113) never reach the output
-  const bool sorted = total_s <= SC_THREADS;  // one thread per entry: sort them by time bucket once
-  int my_tb = -1;
-  if (sorted) {
-    if (tid < total_s) {
-      const int c = tid / n_slices;
-      int isim;
-      const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
-      if (t >= 0.0) {
-        const double ts = slice_time(a.det, t, tid - c * n_slices, n_slices);
-        if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
-          my_tb = (int)ts;
-          atomicAdd(&sh.cum[my_tb], (1ull << 32) | (unsigned long long)key_estimate((int)fmin(t, 511.0), spread));
-        }
-      }
-    }
-  } else {
-    for (int c = tid; c < total; c += SC_THREADS) {
-      int isim;
-      const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
-      if (!(t >= 0.0)) continue;
-      const int est = key_estimate((int)fmin(t, 511.0), spread);
-      for (int sl = 0; sl < n_slices; ++sl) {
-        const double ts = slice_time(a.det, t, sl, n_slices);
-        if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)ts], (1ull << 32) | (unsigned long long)est);
-      }
-    }
-  }
-  __syncthreads();
-  {  // inclusive prefix sum over the 512 buckets: per-thread serial part, wave scan, wave offsets
-    unsigned long long local[BINS_PER_THREAD];
-    unsigned long long v = 0ull;
-#pragma unroll
-    for (int k = 0; k < BINS_PER_THREAD; ++k) {
-      const int bin = tid * BINS_PER_THREAD + k;
-      v += bin < ATTPC_NUM_TB ? sh.cum[bin] : 0ull;
-      local[k] = v;
-    }
-    unsigned long long incl = v;
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned long long up = __shfl_up(incl, off);
-      incl += lane >= off ? up : 0ull;
-    }
-    if (lane == 63) sh.wave_sum[tid >> 6] = incl;
-    __syncthreads();
-    unsigned long long offset = incl - v;
-    for (int w = 0; w < (tid >> 6); ++w) offset += sh.wave_sum[w];
-#pragma unroll
-    for (int k = 0; k < BINS_PER_THREAD; ++k) {
-      const int bin = tid * BINS_PER_THREAD + k;
-      if (bin < ATTPC_NUM_TB) sh.cum[bin] = local[k] + offset;
-    }
-  }
-  __syncthreads();
-
-  if (my_tb >= 0) {  // counting sort: a window is then a contiguous range of perm[]
-    const unsigned int before = my_tb > 0 ? (unsigned int)(sh.cum[my_tb - 1] >> 32) : 0u;
-    sh.perm[before + atomicAdd(&reinterpret_cast<uint32_t*>(&sh.st_ix[0][0])[my_tb], 1u)] = (unsigned short)tid;
-  }
-  if (tid == 0) select_window(sh, 0);
-  __syncthreads();
+  clear_table(sh);  // every flush leaves the table empty again
   unsigned long long my_charge = 0ull, my_keys = 0ull;
-  PHASE_MARK(1);
 
   for (;;) {
-    // the window was chosen by thread 0 before the barrier that ended the previous iteration
-    if (sh.done) break;
-    const int win_a = sh.win_a, win_b = sh.win_b;
-    PHASE_MARK(2);
+    __syncthreads();  // the previous event is finished in every wave
+    if (tid == 0) {
+      int zero = 0;
+      asm volatile("" : "+v"(zero));
+      sh.batch_first = (uint32_t)atomicAdd(&a.out.ctrl[CTRL_NEXT_EVENT + zero], (unsigned long long)a.batch);
+    }
+    __syncthreads();
+    const uint32_t batch_first = sh.batch_first;
+    if (batch_first >= a.n_events) break;
+    const uint32_t batch_end = min(batch_first + a.batch, a.n_events);
+    for (uint32_t e_local = batch_first; e_local < batch_end; ++e_local) {
+      if (e_local != batch_first) __syncthreads();
+      const uint64_t event = a.first_event + e_local;
+      const uint32_t track0 = e_local * (uint32_t)n_sim;
+      // ---- per-event init ----
+      for (int i = tid; i < ATTPC_NUM_TB; i += SC_THREADS) {
+        sh.cum[i] = 0ull;
+        reinterpret_cast<uint32_t*>(&sh.st_ix[0][0])[i] = 0u;  // per-bucket cursors of the entry sort
+      }
+      if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < n_sim; ++k) {
+          sh.cnt[k] = acc;
+          acc += a.trk.counts[track0 + k];
+        }
+        for (int k = n_sim; k <= ATTPC_MAX_SIM; ++k) sh.cnt[k] = acc;
+        sh.win_a = 0; sh.win_b = 0; sh.budget = TARGET_KEYS; sh.overflow = 0; sh.done = 0; sh.ev_failed = 0;
+        sh.wg_samples += (unsigned long long)acc;
+      }
+      __syncthreads();
+      const int total = sh.cnt[ATTPC_MAX_SIM];
+      for (int i = tid; i < n_sim * MAX_BLOCKS_PER_TRACK; i += SC_THREADS) {
+        const int k = i / MAX_BLOCKS_PER_TRACK, b = i - k * MAX_BLOCKS_PER_TRACK;
+        const int n_blk = (sh.cnt[k + 1] - sh.cnt[k] + ARENA_BLK - 1) / ARENA_BLK;
+        sh.blocks[k][b] = b < n_blk ? a.trk.block_table[(size_t)(track0 + k) * MAX_BLOCKS_PER_TRACK + b] : 0;
+      }
+      __syncthreads();
+      PHASE_MARK(0);
 
-    // ---- scatter the window's samples of all nuclei ----
-    // The (sample, slice) list is scanned in chunks of one entry per thread; the entries inside
-    // the window are ranked (ballot prefix + wave totals) and staged densely, so a rows round runs
-    // on a full staging buffer (or on the window's remainder) whatever the order of the samples.
-    int round_lo = 0;  // rank of staging slot 0
-    int filled = 0;    // in-window entries of the chunks before this one
-    bool stop = false;
-    // One rows round over the staged entries.  Returns false when the table is too full.
-    auto rows_round = [&](int n_stage) -> bool {
-      const int n_rows = n_stage * MESH;
-      const int wave = tid >> 6;
-      uint2* __restrict__ queue = sh.queue[wave];
-      const char* __restrict__ lut_bytes = reinterpret_cast<const char*>(lut);
-      const unsigned int row_pitch = 2u * (unsigned int)lut_n;  // bytes per iy row of the transposed LUT
-      unsigned int claimed = 0u;  // new keys of this wave (wave uniform)
-      bool ok = true;
-      for (int row0 = wave * 64; row0 < n_rows; row0 += SC_THREADS) {  // wave-uniform trip count
-        const int row = min(row0 + lane, n_rows - 1);
-        const bool have = row0 + lane < n_rows;
-        const int st = row / MESH;
-        const int i = row - st * MESH;
-        const int tbw = sh.st_tb[st];
-        const bool point = (tbw & (1 << 30)) != 0;
-        const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
-        const double n_el = sh.st_n[st];
-        const double wl = sh.st_wl[st];  // 1 without the longitudinal extension
-        const int ix = sh.st_ix[st][i];
-        // the row's 10 iy indices (5 dwords) and weights (5 x 16 bytes)
-        const uint32_t* __restrict__ iy32 = reinterpret_cast<const uint32_t*>(&sh.st_iy[st][0]);
-        const double2* __restrict__ w2 = reinterpret_cast<const double2*>(&sh.wtab[i * MESH]);
-        int iy[MESH];
-        double w[MESH];
-#pragma unroll
-        for (int j = 0; j < MESH; j += 2) {
-          const uint32_t pair = iy32[j >> 1];
-          iy[j] = (int)(short)(pair & 0xffffu);
-          iy[j + 1] = (int)(short)(pair >> 16);
-          const double2 ww = w2[j >> 1];
-          w[j] = ww.x;
-          w[j + 1] = ww.y;
-        }
-        unsigned int valid = 0u;  // bit j: pixel j is on the LUT
-        int pad[MESH];
-        {
-          // 10 independent gathers in flight (clamped addresses, 32-bit byte offsets from the uniform
-          // base).  The empty asm takes all ten results: without it the compiler sinks each load into
-          // a branch on its select condition and waits there -- ten serial L2 round trips.
-          const unsigned int col = 2u * (unsigned int)max(ix, 0);
-#pragma unroll
-          for (int j = 0; j < MESH; ++j) {
-            const unsigned int off = __umul24((unsigned int)max(iy[j], 0), row_pitch) + col;
-            pad[j] = (int)*reinterpret_cast<const int16_t*>(lut_bytes + off);
-            valid |= iy[j] >= 0 ? (1u << j) : 0u;
-          }
-          asm volatile("" : "+v"(pad[0]), "+v"(pad[1]), "+v"(pad[2]), "+v"(pad[3]), "+v"(pad[4]), "+v"(pad[5]),
-                       "+v"(pad[6]), "+v"(pad[7]), "+v"(pad[8]), "+v"(pad[9]));
-        }
-#ifdef ATTPC_PHASE_TIMERS
-        PHASE_SYNC;
-        PHASE_MARK(8);
-#endif
-        // per-pixel electrons int(pdf h^2 n) (transporter.py:240-246) as u32; the centre pixel is the
-        // largest of the row, so one check bounds every run total of the row below 2^32
-        uint32_t el[MESH];
-#pragma unroll
-        for (int j = 0; j < MESH; ++j) el[j] = (uint32_t)((w[j] * wl) * n_el);  // cvt truncates
-        const bool big = el[MESH / 2] >= (1u << 28);
-        const bool on_plane = have && ix >= 0;
-        // point_transport (transporter.py:123-169, sigma == 0: all electrons straight down, row 0 /
-        // pixel 0 stand for the sample) and rows too large for u32 go pixel by pixel into the table
-        const bool slow = on_plane && (point || big);
-        bool slow_ok = true;
-        if (__any(slow)) {
-          if (slow) {
-#pragma unroll 1
-            for (int j = 0; j < MESH && slow_ok; ++j) {
-              if (!((valid >> j) & 1u) || (point && (i != 0 || j != 0))) continue;
-              const unsigned int off = __umul24((unsigned int)iy[j], row_pitch) + 2u * (unsigned int)ix;
-              const int p = (int)*reinterpret_cast<const int16_t*>(lut_bytes + off);
-              const double q = ((point ? 1.0 : sh.wtab[i * MESH + j]) * wl) * n_el;
-              if (p >= 0) slow_ok = table_add(sh, word_hi | (uint32_t)p, (unsigned long long)q);
+      // ---- histogram of kept samples per time bucket (all nuclei), then its prefix sum ----
+      const int total_s = total * n_slices;  // entries = samples x slices
+      // t < 0 (sigma_t would be NaN: undefined in the reference) and tb >= 512 (removed by the
+      // 0 <= tb < 512 mask of simulator.py:111-113) never reach the output
+      const bool sorted = total_s <= SC_THREADS;  // one thread per entry: sort them by time bucket once
+      int my_tb = -1;
+      if (sorted) {
+        if (tid < total_s) {
+          const int c = tid / n_slices;
+          int isim;
+          const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
+          if (t >= 0.0) {
+            const double ts = slice_time(a.det, t, tid - c * n_slices, n_slices);
+            if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
+              my_tb = (int)ts;
+              atomicAdd(&sh.cum[my_tb], (1ull << 32) | (unsigned long long)key_estimate((int)fmin(t, 511.0), spread));
             }
           }
         }
-        const bool live = on_plane && !slow;
-        // merge runs of equal pads: a run's total sits with its last pixel
-        uint32_t run_q[MESH];
-        uint32_t ends = 0u;  // bit j: pixel j ends a run on a real pad
-        {
-          uint32_t acc = 0u;
-#pragma unroll
-          for (int j = 0; j < MESH; ++j) {
-            pad[j] = (live && ((valid >> j) & 1u)) ? pad[j] : -1;
-          }
-#pragma unroll
-          for (int j = 0; j < MESH; ++j) {
-            acc += pad[j] >= 0 ? el[j] : 0u;
-            const bool last = (j == MESH - 1) || (pad[j < MESH - 1 ? j + 1 : j] != pad[j]);
-            run_q[j] = acc;
-            ends |= (last && pad[j] >= 0) ? (1u << j) : 0u;
-            acc = last ? 0u : acc;
-          }
-        }
-#ifdef ATTPC_PHASE_TIMERS
-        asm volatile("" ::"v"(ends), "v"(run_q[9]));
-        PHASE_SYNC;
-        PHASE_MARK(9);
-#endif
-        // queue positions: exclusive prefix of the run counts (0..10, four bits) over the wave from
-        // four ballots and mbcnt -- no cross-lane data movement
-        const uint32_t n_runs = (uint32_t)__popc(ends);
-        int first = 0, wave_total = 0;
-#pragma unroll
-        for (int bit = 0; bit < 4; ++bit) {
-          const unsigned long long m = __ballot((n_runs >> bit) & 1u);
-          first += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << bit;
-          wave_total += (int)__popcll(m) << bit;
-        }
-        for (int pass0 = 0; pass0 < wave_total; pass0 += WAVE_QUEUE) {
-          int e = first - pass0;  // queue position of this lane's next run in this pass
-#pragma unroll
-          for (int j = 0; j < MESH; ++j) {
-            const bool put = ((ends >> j) & 1u) && e >= 0 && e < WAVE_QUEUE;
-            queue[put ? e : WAVE_QUEUE] = make_uint2(word_hi | (uint32_t)pad[j], run_q[j]);  // WAVE_QUEUE = dump slot
-            e += (int)((ends >> j) & 1u);
-          }
-          const int n_q = min(wave_total - pass0, WAVE_QUEUE);
-#ifdef ATTPC_PHASE_TIMERS
-          PHASE_SYNC;
-          PHASE_MARK(10);
-#endif
-          for (int k0 = 0; k0 < n_q && ok; k0 += 64) {  // wave uniform
-            const uint2 item = queue[min(k0 + lane, n_q - 1)];
-            ok = wave_insert(sh, item.x, item.y, k0 + lane < n_q, claimed);
-          }
-#ifdef ATTPC_PHASE_TIMERS
-          PHASE_SYNC;
-          PHASE_MARK(11);
-#endif
-          if (!ok) break;
-        }
-        ok = ok && !__any(!slow_ok);  // the slow path fails in single lanes
-        if (!ok) break;    // table too full: the whole wave stops together
-      }
-      if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);  // rows of the window's flush
-      return ok;
-    };
-
-    // one (sample, slice) entry -> staging slot: sigma_t and the LUT indices of its 20 mesh lines
-    auto stage_entry = [&](int slot, double2 xy, double2 tn, int isim, int sl) {
-      const int tb = (int)slice_time(a.det, tn.x, sl, n_slices);  // transporter.py:238
-      const double sigma = sqrt(2.0 * a.det.diffusion * a.det.dv * tn.x / a.det.efield);  // :301
-      const double lo_mm = (double)lut_lo, hi_mm = (double)(lut_lo + lut_n);
-      // numpy.linspace(c - 3 sigma, c + 3 sigma, 10) (:221-227) and position_to_index
-      // (:107-118: whole-mm floor, low edge inclusive, high edge exclusive) per mesh line
-      const double xlo = xy.x - 3.0 * sigma, xhi = xy.x + 3.0 * sigma;
-      const double ylo = xy.y - 3.0 * sigma, yhi = xy.y + 3.0 * sigma;
-      const double sx = (xhi - xlo) / (double)(MESH - 1), sy = (yhi - ylo) / (double)(MESH - 1);
-#pragma unroll
-      for (int i = 0; i < MESH; ++i) {
-        const double x = (i == MESH - 1) ? xhi : (double)i * sx + xlo;
-        const double y = (i == MESH - 1) ? yhi : (double)i * sy + ylo;
-        const double fx = floor(x * 1000.0), fy = floor(y * 1000.0);
-        sh.st_ix[slot][i] = (fx >= lo_mm && fx < hi_mm) ? (short)((int)fx - lut_lo) : (short)-1;
-        sh.st_iy[slot][i] = (fy >= lo_mm && fy < hi_mm) ? (short)((int)fy - lut_lo) : (short)-1;
-      }
-      sh.st_n[slot] = tn.y;
-      sh.st_wl[slot] = n_slices == 1 ? 1.0 : a.det.long_weights[sl];
-      sh.st_tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
-    };
-    if (sorted) {  // the window is perm[win_r0 .. win_r0 + win_n): stage it densely, STAGE entries per round
-      const int r0 = sh.win_r0, n_win = sh.win_n;
-      for (int base = 0; base < n_win; base += STAGE) {
-        const int n_stage = min(STAGE, n_win - base);
-        if (tid < n_stage) {
-          const int cs = (int)sh.perm[r0 + base + tid];
-          const int c = cs / n_slices;
+      } else {
+        for (int c = tid; c < total; c += SC_THREADS) {
           int isim;
-          const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
-          stage_entry(tid, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1], isim,
-                      cs - c * n_slices);
+          const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
+          if (!(t >= 0.0)) continue;
+          const int est = key_estimate((int)fmin(t, 511.0), spread);
+          for (int sl = 0; sl < n_slices; ++sl) {
+            const double ts = slice_time(a.det, t, sl, n_slices);
+            if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)ts], (1ull << 32) | (unsigned long long)est);
+          }
         }
-        __syncthreads();
-        PHASE_MARK(3);
-        PHASE_COUNT(12, 1);
-        PHASE_COUNT(13, n_stage);
-        PHASE_COUNT(14, (n_stage * MESH + SC_THREADS - 1) / SC_THREADS);
-        const bool ok = rows_round(n_stage);
-        if (!ok) sh.overflow = 1;
-        __syncthreads();
-        PHASE_MARK(4);
-        if (sh.overflow) break;  // uniform: every thread sees the flag after the barrier
       }
-    }
-    for (int c0 = 0, chunk = 0; !sorted && c0 < total_s && !stop; c0 += SC_THREADS, ++chunk) {
-      bool in_win = false;
-      double2 xy = {0.0, 0.0}, tn = {0.0, 0.0};
-      int isim = 0, sl = 0;
-      if (c0 + tid < total_s) {  // the whole record in one round trip, in the window or not
-        const int c = (c0 + tid) / n_slices;
-        sl = (c0 + tid) - c * n_slices;
-        const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
-        xy = reinterpret_cast<const double2*>(rec)[0];
-        tn = reinterpret_cast<const double2*>(rec)[1];
-        const double ts = tn.x >= 0.0 ? slice_time(a.det, tn.x, sl, n_slices) : -1.0;
-        in_win = ts >= 0.0 && ts < (double)ATTPC_NUM_TB && (int)ts >= win_a && (int)ts < win_b;
-      }
-      const unsigned long long bal = __ballot(in_win);
-      if (lane == 0) sh.stage_sum[chunk & 1][tid >> 6] = __popcll(bal);
       __syncthreads();
-      // rank among the window's entries; entries outside the window never match a staging slot
-      int rank = in_win ? filled + (int)__popcll(bal & ((1ull << lane) - 1ull)) : -(1 << 30);
-      int filled_new = filled;
+      {  // inclusive prefix sum over the 512 buckets: per-thread serial part, wave scan, wave offsets
+        unsigned long long local[BINS_PER_THREAD];
+        unsigned long long v = 0ull;
 #pragma unroll
-      for (int w = 0; w < N_WAVES; ++w) {
-        const int n_w = sh.stage_sum[chunk & 1][w];
-        rank += w < (tid >> 6) ? n_w : 0;
-        filled_new += n_w;
+        for (int k = 0; k < BINS_PER_THREAD; ++k) {
+          const int bin = tid * BINS_PER_THREAD + k;
+          v += bin < ATTPC_NUM_TB ? sh.cum[bin] : 0ull;
+          local[k] = v;
+        }
+        unsigned long long incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned long long up = __shfl_up(incl, off);
+          incl += lane >= off ? up : 0ull;
+        }
+        if (lane == 63) sh.wave_sum[tid >> 6] = incl;
+        __syncthreads();
+        unsigned long long offset = incl - v;
+        for (int w = 0; w < (tid >> 6); ++w) offset += sh.wave_sum[w];
+#pragma unroll
+        for (int k = 0; k < BINS_PER_THREAD; ++k) {
+          const int bin = tid * BINS_PER_THREAD + k;
+          if (bin < ATTPC_NUM_TB) sh.cum[bin] = local[k] + offset;
+        }
       }
-      const bool last_chunk = c0 + SC_THREADS >= total_s;
-      if (rank - round_lo >= 0 && rank - round_lo < STAGE) stage_entry(rank - round_lo, xy, tn, isim, sl);
+      __syncthreads();
+
+      if (my_tb >= 0) {  // counting sort: a window is then a contiguous range of perm[]
+        const unsigned int before = my_tb > 0 ? (unsigned int)(sh.cum[my_tb - 1] >> 32) : 0u;
+        sh.perm[before + atomicAdd(&reinterpret_cast<uint32_t*>(&sh.st_ix[0][0])[my_tb], 1u)] = (unsigned short)tid;
+      }
+      if (tid == 0) select_window(sh, 0);
+      __syncthreads();
+      PHASE_MARK(1);
+
       for (;;) {
-        const int pending = filled_new - round_lo;  // staged entries, workgroup uniform
-        if (pending < STAGE && !(last_chunk && pending > 0)) break;  // keep filling / nothing left
-        const int n_stage = min(pending, STAGE);
-        __syncthreads();
-        PHASE_MARK(3);
-        PHASE_COUNT(12, 1);                                          // rows rounds
-        PHASE_COUNT(13, n_stage);                                    // staged entries
-        PHASE_COUNT(14, (n_stage * MESH + SC_THREADS - 1) / SC_THREADS);  // 64-row passes of the busiest wave
+        // the window was chosen by thread 0 before the barrier that ended the previous iteration
+        if (sh.done) break;
+        const int win_a = sh.win_a, win_b = sh.win_b;
+        PHASE_MARK(2);
 
-        // rows -> runs -> this wave's queue -> table, 64 mesh rows per wave at a time
-        const bool ok = rows_round(n_stage);
-        if (!ok) sh.overflow = 1;
-        __syncthreads();
-        PHASE_MARK(4);
-        if (sh.overflow) {  // uniform: every thread sees the flag after the barrier
-          stop = true;
-          break;
-        }
-        round_lo += n_stage;
-        if (filled_new <= round_lo) break;
-        if (rank - round_lo >= 0 && rank - round_lo < STAGE) {  // rest of this chunk: the records were not
-          const int c = (c0 + tid) / n_slices;                   // kept in registers across the rows phase
-          int isim2;
-          const double* rec = sample_ptr(sh, arena, n_sim, c, isim2);
-          stage_entry(rank - round_lo, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1],
-                      isim2, (c0 + tid) - c * n_slices);
-        }
-      }
-      filled = filled_new;
-    }
-
-    if (sh.overflow) {
-      __syncthreads();
-      clear_table(sh);
-      if (tid == 0) {
-        sh.retried++;
-        if (win_b - win_a <= 1) {
-          sh.failed = 1;          // one time bucket alone exceeds the table: not representable
-          sh.overflow = 0;
-          sh.win_b = win_a + 1;   // skip this bucket
-          sh.budget = TARGET_KEYS;
-        } else {
-          sh.budget = sh.win_samples / 2 > 0 ? sh.win_samples / 2 : 1;
-        }
-        const int from = sh.overflow ? sh.win_a : sh.win_b;  // overflow: same start, smaller budget
-        sh.overflow = 0;
-        sh.n_keys = 0u;
-        select_window(sh, from);
-      }
-      __syncthreads();
-      continue;
-    }
-
-    // ---- flush: reserve one contiguous range of rows, compact the occupied slots, write rows ----
-    // (the last barrier of the rows phase made every claim visible: n_keys is final)
-    const unsigned int n_rows = sh.n_keys;
-    unsigned long long g_base = 0ull, g_seg = 0ull;
-    if (tid == 0) {
-      sh.wg_cursor = 0u;
-      if (n_rows) {  // two independent global atomics in flight while the slots are compacted.
-        // The address is made opaque (a VGPR the compiler cannot prove uniform): with a uniform
-        // address LLVM's atomic optimizer rewrites the add into "one lane adds, readfirstlane the
-        // result", and the readfirstlane waits for each atomic's round trip right here.
-        int zero = 0;
-        asm volatile("" : "+v"(zero));
-        g_base = atomicAdd(&a.out.ctrl[zero], (unsigned long long)n_rows);
-        g_seg = atomicAdd(&a.out.ctrl[zero + 1], 1ull);
-      }
-    }
-    __syncthreads();
-    {  // every wave compacts its own contiguous slice of the table with a single LDS atomic
-      constexpr int PER_WAVE = HASH_CAP / N_WAVES;
-      constexpr int ITERS = PER_WAVE / 64;
-      const int wave = tid >> 6;
-      unsigned long long occ_mask[ITERS];
-      unsigned int cnt = 0;
+        // ---- scatter the window's samples of all nuclei ----
+        // The (sample, slice) list is scanned in chunks of one entry per thread; the entries inside
+        // the window are ranked (ballot prefix + wave totals) and staged densely, so a rows round runs
+        // on a full staging buffer (or on the window's remainder) whatever the order of the samples.
+        int round_lo = 0;  // rank of staging slot 0
+        int filled = 0;    // in-window entries of the chunks before this one
+        bool stop = false;
+        // One rows round over the staged entries.  Returns false when the table is too full.
+        auto rows_round = [&](int n_stage) -> bool {
+          const int n_rows = n_stage * MESH;
+          const int wave = tid >> 6;
+          uint2* __restrict__ queue = sh.queue[wave];
+          const char* __restrict__ lut_bytes = reinterpret_cast<const char*>(lut);
+          const unsigned int row_pitch = 2u * (unsigned int)lut_n;  // bytes per iy row of the transposed LUT
+          unsigned int claimed = 0u;  // new keys of this wave (wave uniform)
+          bool ok = true;
+          for (int row0 = wave * 64; row0 < n_rows; row0 += SC_THREADS) {  // wave-uniform trip count
+            const int row = min(row0 + lane, n_rows - 1);
+            const bool have = row0 + lane < n_rows;
+            const int st = row / MESH;
+            const int i = row - st * MESH;
+            const int tbw = sh.st_tb[st];
+            const bool point = (tbw & (1 << 30)) != 0;
+            const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
+            const double n_el = sh.st_n[st];
+            const double wl = sh.st_wl[st];  // 1 without the longitudinal extension
+            const int ix = sh.st_ix[st][i];
+            // the row's 10 iy indices (5 dwords) and weights (5 x 16 bytes)
+            const uint32_t* __restrict__ iy32 = reinterpret_cast<const uint32_t*>(&sh.st_iy[st][0]);
+            const double2* __restrict__ w2 = reinterpret_cast<const double2*>(&sh.wtab[i * MESH]);
+            int iy[MESH];
+            double w[MESH];
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        occ_mask[it] = __ballot(sh.keys[wave * PER_WAVE + it * 64 + lane] != EMPTY);
-        cnt += (unsigned int)__popcll(occ_mask[it]);
-      }
-      unsigned int wbase = 0;
-      if (lane == 0 && cnt) wbase = atomicAdd(&sh.wg_cursor, cnt);
-      wbase = __shfl(wbase, 0);
-      uint32_t* __restrict__ list = reinterpret_cast<uint32_t*>(&sh.queue[0][0]);
+            for (int j = 0; j < MESH; j += 2) {
+              const uint32_t pair = iy32[j >> 1];
+              iy[j] = (int)(short)(pair & 0xffffu);
+              iy[j + 1] = (int)(short)(pair >> 16);
+              const double2 ww = w2[j >> 1];
+              w[j] = ww.x;
+              w[j + 1] = ww.y;
+            }
+            unsigned int valid = 0u;  // bit j: pixel j is on the LUT
+            int pad[MESH];
+            {
+              // 10 independent gathers in flight (clamped addresses, 32-bit byte offsets from the uniform
+              // base).  The empty asm takes all ten results: without it the compiler sinks each load into
+              // a branch on its select condition and waits there -- ten serial L2 round trips.
+              const unsigned int col = 2u * (unsigned int)max(ix, 0);
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        const unsigned long long m = occ_mask[it];
-        if ((m >> lane) & 1ull)
-          list[wbase + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(wave * PER_WAVE + it * 64 + lane);
-        wbase += (unsigned int)__popcll(m);
-      }
-    }
-    PHASE_MARK(15);  // compaction done (wave 0)
-    if (tid == 0) {
-      unsigned long long base = 0ull;
-      if (n_rows) {
-        base = g_base;
+              for (int j = 0; j < MESH; ++j) {
+                const unsigned int off = __umul24((unsigned int)max(iy[j], 0), row_pitch) + col;
+                pad[j] = (int)*reinterpret_cast<const int16_t*>(lut_bytes + off);
+                valid |= iy[j] >= 0 ? (1u << j) : 0u;
+              }
+              asm volatile("" : "+v"(pad[0]), "+v"(pad[1]), "+v"(pad[2]), "+v"(pad[3]), "+v"(pad[4]), "+v"(pad[5]),
+                           "+v"(pad[6]), "+v"(pad[7]), "+v"(pad[8]), "+v"(pad[9]));
+            }
 #ifdef ATTPC_PHASE_TIMERS
-        asm volatile("" ::"v"(g_base), "v"(g_seg));
-        PHASE_SYNC;
-        PHASE_MARK(16);  // global atomics returned
+            PHASE_SYNC;
+            PHASE_MARK(8);
 #endif
-        if (base + n_rows > (unsigned long long)a.out.capacity || g_seg >= (unsigned long long)a.out.seg_capacity) {
-          a.out.ctrl[6] = 1ull;  // out of capacity: host re-runs the chunk with larger buffers
-          base = ~0ull;
-        } else {
-          Segment sg;
-          sg.event = (int32_t)e_local;
-          sg.count = (int32_t)n_rows;
-          sg.offset = (int64_t)base;
-          a.out.segments[g_seg] = sg;
+            // per-pixel electrons int(pdf h^2 n) (transporter.py:240-246) as u32; the centre pixel is the
+            // largest of the row, so one check bounds every run total of the row below 2^32
+            uint32_t el[MESH];
+#pragma unroll
+            for (int j = 0; j < MESH; ++j) el[j] = (uint32_t)((w[j] * wl) * n_el);  // cvt truncates
+            const bool big = el[MESH / 2] >= (1u << 28);
+            const bool on_plane = have && ix >= 0;
+            // point_transport (transporter.py:123-169, sigma == 0: all electrons straight down, row 0 /
+            // pixel 0 stand for the sample) and rows too large for u32 go pixel by pixel into the table
+            const bool slow = on_plane && (point || big);
+            bool slow_ok = true;
+            if (__any(slow)) {
+              if (slow) {
+#pragma unroll 1
+                for (int j = 0; j < MESH && slow_ok; ++j) {
+                  if (!((valid >> j) & 1u) || (point && (i != 0 || j != 0))) continue;
+                  const unsigned int off = __umul24((unsigned int)iy[j], row_pitch) + 2u * (unsigned int)ix;
+                  const int p = (int)*reinterpret_cast<const int16_t*>(lut_bytes + off);
+                  const double q = ((point ? 1.0 : sh.wtab[i * MESH + j]) * wl) * n_el;
+                  if (p >= 0) slow_ok = table_add(sh, word_hi | (uint32_t)p, (unsigned long long)q);
+                }
+              }
+            }
+            const bool live = on_plane && !slow;
+            // merge runs of equal pads: a run's total sits with its last pixel
+            uint32_t run_q[MESH];
+            uint32_t ends = 0u;  // bit j: pixel j ends a run on a real pad
+            {
+              uint32_t acc = 0u;
+#pragma unroll
+              for (int j = 0; j < MESH; ++j) {
+                pad[j] = (live && ((valid >> j) & 1u)) ? pad[j] : -1;
+              }
+#pragma unroll
+              for (int j = 0; j < MESH; ++j) {
+                acc += pad[j] >= 0 ? el[j] : 0u;
+                const bool last = (j == MESH - 1) || (pad[j < MESH - 1 ? j + 1 : j] != pad[j]);
+                run_q[j] = acc;
+                ends |= (last && pad[j] >= 0) ? (1u << j) : 0u;
+                acc = last ? 0u : acc;
+              }
+            }
+#ifdef ATTPC_PHASE_TIMERS
+            asm volatile("" ::"v"(ends), "v"(run_q[9]));
+            PHASE_SYNC;
+            PHASE_MARK(9);
+#endif
+            // queue positions: exclusive prefix of the run counts (0..10, four bits) over the wave from
+            // four ballots and mbcnt -- no cross-lane data movement
+            const uint32_t n_runs = (uint32_t)__popc(ends);
+            int first = 0, wave_total = 0;
+#pragma unroll
+            for (int bit = 0; bit < 4; ++bit) {
+              const unsigned long long m = __ballot((n_runs >> bit) & 1u);
+              first += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << bit;
+              wave_total += (int)__popcll(m) << bit;
+            }
+            for (int pass0 = 0; pass0 < wave_total; pass0 += WAVE_QUEUE) {
+              int e = first - pass0;  // queue position of this lane's next run in this pass
+#pragma unroll
+              for (int j = 0; j < MESH; ++j) {
+                const bool put = ((ends >> j) & 1u) && e >= 0 && e < WAVE_QUEUE;
+                queue[put ? e : WAVE_QUEUE] = make_uint2(word_hi | (uint32_t)pad[j], run_q[j]);  // WAVE_QUEUE = dump slot
+                e += (int)((ends >> j) & 1u);
+              }
+              const int n_q = min(wave_total - pass0, WAVE_QUEUE);
+#ifdef ATTPC_PHASE_TIMERS
+              PHASE_SYNC;
+              PHASE_MARK(10);
+#endif
+              for (int k0 = 0; k0 < n_q && ok; k0 += 64) {  // wave uniform
+                const uint2 item = queue[min(k0 + lane, n_q - 1)];
+                ok = wave_insert(sh, item.x, item.y, k0 + lane < n_q, claimed);
+              }
+#ifdef ATTPC_PHASE_TIMERS
+              PHASE_SYNC;
+              PHASE_MARK(11);
+#endif
+              if (!ok) break;
+            }
+            ok = ok && !__any(!slow_ok);  // the slow path fails in single lanes
+            if (!ok) break;    // table too full: the whole wave stops together
+          }
+          if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);  // rows of the window's flush
+          return ok;
+        };
+
+        // one (sample, slice) entry -> staging slot: sigma_t and the LUT indices of its 20 mesh lines
+        auto stage_entry = [&](int slot, double2 xy, double2 tn, int isim, int sl) {
+          const int tb = (int)slice_time(a.det, tn.x, sl, n_slices);  // transporter.py:238
+          const double sigma = sqrt(2.0 * a.det.diffusion * a.det.dv * tn.x / a.det.efield);  // :301
+          const double lo_mm = (double)lut_lo, hi_mm = (double)(lut_lo + lut_n);
+          // numpy.linspace(c - 3 sigma, c + 3 sigma, 10) (:221-227) and position_to_index
+          // (:107-118: whole-mm floor, low edge inclusive, high edge exclusive) per mesh line
+          const double xlo = xy.x - 3.0 * sigma, xhi = xy.x + 3.0 * sigma;
+          const double ylo = xy.y - 3.0 * sigma, yhi = xy.y + 3.0 * sigma;
+          const double sx = (xhi - xlo) / (double)(MESH - 1), sy = (yhi - ylo) / (double)(MESH - 1);
+#pragma unroll
+          for (int i = 0; i < MESH; ++i) {
+            const double x = (i == MESH - 1) ? xhi : (double)i * sx + xlo;
+            const double y = (i == MESH - 1) ? yhi : (double)i * sy + ylo;
+            const double fx = floor(x * 1000.0), fy = floor(y * 1000.0);
+            sh.st_ix[slot][i] = (fx >= lo_mm && fx < hi_mm) ? (short)((int)fx - lut_lo) : (short)-1;
+            sh.st_iy[slot][i] = (fy >= lo_mm && fy < hi_mm) ? (short)((int)fy - lut_lo) : (short)-1;
+          }
+          sh.st_n[slot] = tn.y;
+          sh.st_wl[slot] = n_slices == 1 ? 1.0 : a.det.long_weights[sl];
+          sh.st_tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
+        };
+        if (sorted) {  // the window is perm[win_r0 .. win_r0 + win_n): stage it densely, STAGE entries per round
+          const int r0 = sh.win_r0, n_win = sh.win_n;
+          for (int base = 0; base < n_win; base += STAGE) {
+            const int n_stage = min(STAGE, n_win - base);
+            if (tid < n_stage) {
+              const int cs = (int)sh.perm[r0 + base + tid];
+              const int c = cs / n_slices;
+              int isim;
+              const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
+              stage_entry(tid, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1], isim,
+                          cs - c * n_slices);
+            }
+            __syncthreads();
+            PHASE_MARK(3);
+            PHASE_COUNT(12, 1);
+            PHASE_COUNT(13, n_stage);
+            PHASE_COUNT(14, (n_stage * MESH + SC_THREADS - 1) / SC_THREADS);
+            const bool ok = rows_round(n_stage);
+            if (!ok) sh.overflow = 1;
+            __syncthreads();
+            PHASE_MARK(4);
+            if (sh.overflow) break;  // uniform: every thread sees the flag after the barrier
+          }
         }
+        for (int c0 = 0, chunk = 0; !sorted && c0 < total_s && !stop; c0 += SC_THREADS, ++chunk) {
+          bool in_win = false;
+          double2 xy = {0.0, 0.0}, tn = {0.0, 0.0};
+          int isim = 0, sl = 0;
+          if (c0 + tid < total_s) {  // the whole record in one round trip, in the window or not
+            const int c = (c0 + tid) / n_slices;
+            sl = (c0 + tid) - c * n_slices;
+            const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
+            xy = reinterpret_cast<const double2*>(rec)[0];
+            tn = reinterpret_cast<const double2*>(rec)[1];
+            const double ts = tn.x >= 0.0 ? slice_time(a.det, tn.x, sl, n_slices) : -1.0;
+            in_win = ts >= 0.0 && ts < (double)ATTPC_NUM_TB && (int)ts >= win_a && (int)ts < win_b;
+          }
+          const unsigned long long bal = __ballot(in_win);
+          if (lane == 0) sh.stage_sum[chunk & 1][tid >> 6] = __popcll(bal);
+          __syncthreads();
+          // rank among the window's entries; entries outside the window never match a staging slot
+          int rank = in_win ? filled + (int)__popcll(bal & ((1ull << lane) - 1ull)) : -(1 << 30);
+          int filled_new = filled;
+#pragma unroll
+          for (int w = 0; w < N_WAVES; ++w) {
+            const int n_w = sh.stage_sum[chunk & 1][w];
+            rank += w < (tid >> 6) ? n_w : 0;
+            filled_new += n_w;
+          }
+          const bool last_chunk = c0 + SC_THREADS >= total_s;
+          if (rank - round_lo >= 0 && rank - round_lo < STAGE) stage_entry(rank - round_lo, xy, tn, isim, sl);
+          for (;;) {
+            const int pending = filled_new - round_lo;  // staged entries, workgroup uniform
+            if (pending < STAGE && !(last_chunk && pending > 0)) break;  // keep filling / nothing left
+            const int n_stage = min(pending, STAGE);
+            __syncthreads();
+            PHASE_MARK(3);
+            PHASE_COUNT(12, 1);                                          // rows rounds
+            PHASE_COUNT(13, n_stage);                                    // staged entries
+            PHASE_COUNT(14, (n_stage * MESH + SC_THREADS - 1) / SC_THREADS);  // 64-row passes of the busiest wave
+
+            // rows -> runs -> this wave's queue -> table, 64 mesh rows per wave at a time
+            const bool ok = rows_round(n_stage);
+            if (!ok) sh.overflow = 1;
+            __syncthreads();
+            PHASE_MARK(4);
+            if (sh.overflow) {  // uniform: every thread sees the flag after the barrier
+              stop = true;
+              break;
+            }
+            round_lo += n_stage;
+            if (filled_new <= round_lo) break;
+            if (rank - round_lo >= 0 && rank - round_lo < STAGE) {  // rest of this chunk: the records were not
+              const int c = (c0 + tid) / n_slices;                   // kept in registers across the rows phase
+              int isim2;
+              const double* rec = sample_ptr(sh, arena, n_sim, c, isim2);
+              stage_entry(rank - round_lo, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1],
+                          isim2, (c0 + tid) - c * n_slices);
+            }
+          }
+          filled = filled_new;
+        }
+
+        if (sh.overflow) {
+          __syncthreads();
+          clear_table(sh);
+          if (tid == 0) {
+            sh.retried++;
+            if (win_b - win_a <= 1) {
+              if (!sh.ev_failed) sh.failed++;  // events with a time bucket that alone exceeds the table
+              sh.ev_failed = 1;
+              sh.overflow = 0;
+              sh.win_b = win_a + 1;   // skip this bucket
+              sh.budget = TARGET_KEYS;
+            } else {
+              sh.budget = sh.win_samples / 2 > 0 ? sh.win_samples / 2 : 1;
+            }
+            const int from = sh.overflow ? sh.win_a : sh.win_b;  // overflow: same start, smaller budget
+            sh.overflow = 0;
+            sh.n_keys = 0u;
+            select_window(sh, from);
+          }
+          __syncthreads();
+          continue;
+        }
+
+        // ---- flush: reserve one contiguous range of rows, compact the occupied slots, write rows ----
+        // (the last barrier of the rows phase made every claim visible: n_keys is final)
+        const unsigned int n_rows = sh.n_keys;
+        unsigned long long g_base = 0ull, g_seg = 0ull;
+        if (tid == 0) {
+          sh.wg_cursor = 0u;
+          if (n_rows) {
+            // Output rows and segment slots come from blocks this workgroup reserved earlier: one
+            // global atomic per ~row_block rows instead of two per window (a hot-address atomic costs
+            // microseconds here, and every wave waits for it at the next barrier).  The unused tail of
+            // a block stays a hole; consumers find rows through the segment list only.
+            int zero = 0;
+            asm volatile("" : "+v"(zero));  // opaque: keeps LLVM's atomic optimizer (readfirstlane) away
+            if (sh.row_cur + n_rows > sh.row_end) {
+              const unsigned long long need = max((unsigned long long)a.row_block, (unsigned long long)n_rows);
+              sh.row_cur = atomicAdd(&a.out.ctrl[zero], need);
+              sh.row_end = sh.row_cur + need;
+            }
+            g_base = sh.row_cur;
+            sh.row_cur += n_rows;
+            if (sh.seg_cur >= sh.seg_end) {
+              sh.seg_cur = atomicAdd(&a.out.ctrl[zero + 1], (unsigned long long)SEG_BLOCK);
+              sh.seg_end = sh.seg_cur + SEG_BLOCK;
+            }
+            g_seg = sh.seg_cur++;
+            sh.wg_rows += n_rows;
+          }
+        }
+        __syncthreads();
+        PHASE_MARK(19);
+        {  // every wave compacts its own contiguous slice of the table with a single LDS atomic
+          constexpr int PER_WAVE = HASH_CAP / N_WAVES;
+          constexpr int ITERS = PER_WAVE / 64;
+          const int wave = tid >> 6;
+          unsigned long long occ_mask[ITERS];
+          unsigned int cnt = 0;
+#pragma unroll
+          for (int it = 0; it < ITERS; ++it) {
+            occ_mask[it] = __ballot(sh.keys[wave * PER_WAVE + it * 64 + lane] != EMPTY);
+            cnt += (unsigned int)__popcll(occ_mask[it]);
+          }
+          unsigned int wbase = 0;
+          if (lane == 0 && cnt) wbase = atomicAdd(&sh.wg_cursor, cnt);
+          wbase = __shfl(wbase, 0);
+          uint32_t* __restrict__ list = reinterpret_cast<uint32_t*>(&sh.queue[0][0]);
+#pragma unroll
+          for (int it = 0; it < ITERS; ++it) {
+            const unsigned long long m = occ_mask[it];
+            if ((m >> lane) & 1ull)
+              list[wbase + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(wave * PER_WAVE + it * 64 + lane);
+            wbase += (unsigned int)__popcll(m);
+          }
+        }
+        PHASE_MARK(15);  // compaction done (wave 0)
+        if (tid == 0) {
+          unsigned long long base = 0ull;
+          if (n_rows) {
+            base = g_base;
+#ifdef ATTPC_PHASE_TIMERS
+            asm volatile("" ::"v"(g_base), "v"(g_seg));
+            PHASE_SYNC;
+            PHASE_MARK(16);  // global atomics returned
+#endif
+            if (base + n_rows > (unsigned long long)a.out.capacity || g_seg >= (unsigned long long)a.out.seg_capacity) {
+              a.out.ctrl[6] = 1ull;  // out of capacity: host re-runs the chunk with larger buffers
+              base = ~0ull;
+            } else {
+              Segment sg;
+              sg.event = (int32_t)e_local;
+              sg.count = (int32_t)n_rows;
+              sg.offset = (int64_t)base;
+              a.out.segments[g_seg] = sg;
+            }
+          }
+          sh.base = base;
+          sh.n_keys = 0u;
+          // adapt the estimate to this event: observed keys per estimated key of the last window
+          const int ratio_x16 = sh.win_samples > 0 ? (int)(n_rows * 16u) / sh.win_samples : 16;
+          sh.budget = ratio_x16 > 0 ? TARGET_KEYS * 16 / ratio_x16 : TARGET_KEYS;
+          sh.budget = min(max(sh.budget, TARGET_KEYS / 8), TARGET_KEYS * 4);
+          PHASE_MARK(17);  // segment written
+          select_window(sh, win_b);  // the next window, published by the barrier after the row stores
+          PHASE_MARK(18);
+        }
+        __syncthreads();
+        PHASE_MARK(6);
+        const unsigned long long base = sh.base;
+        for (unsigned int r = tid; r < n_rows; r += SC_THREADS) {
+          const uint32_t slot = reinterpret_cast<const uint32_t*>(&sh.queue[0][0])[r];
+          const uint32_t word = sh.keys[slot];
+          const unsigned long long q = sh.chg[slot];
+          sh.keys[slot] = EMPTY;
+          sh.chg[slot] = 0ull;
+          const uint32_t key = word & KEY_MASK;
+          const int pad = (int)(key & 0x3fffu), tb = (int)(key >> 14);
+          my_charge += q;
+          my_keys += (event << 24) + (unsigned long long)key;
+          if (base != ~0ull) {
+            const unsigned long long row = base + r;
+            double ua, ub;
+            rng_pair(a.seed, event, key, DOMAIN_JITTER, ua, ub);  // simulator.py:108
+            double* o = a.out.points + row * 3;
+            o[0] = (double)pad;
+            o[1] = (double)tb + ua;
+            o[2] = (double)q;
+            a.out.labels[row] = (int64_t)sh.label_of[word >> 24];  // from LDS: a global load here would
+                                                                    // make every store wait (one vmcnt)
+          }
+        }
+        // no barrier here: the next window was published before the row stores, and the first barrier of
+        // its staging orders these LDS resets before any new insert while the sample loads of that
+        // staging overlap the store acknowledgements
+        PHASE_MARK(7);
       }
-      sh.base = base;
-      sh.n_keys = 0u;
-      // adapt the estimate to this event: observed keys per estimated key of the last window
-      const int ratio_x16 = sh.win_samples > 0 ? (int)(n_rows * 16u) / sh.win_samples : 16;
-      sh.budget = ratio_x16 > 0 ? TARGET_KEYS * 16 / ratio_x16 : TARGET_KEYS;
-      sh.budget = min(max(sh.budget, TARGET_KEYS / 8), TARGET_KEYS * 4);
-      PHASE_MARK(17);  // segment written
-      select_window(sh, win_b);  // the next window, published by the barrier after the row stores
-      PHASE_MARK(18);
     }
-    __syncthreads();
-    PHASE_MARK(6);
-    const unsigned long long base = sh.base;
-    for (unsigned int r = tid; r < n_rows; r += SC_THREADS) {
-      const uint32_t slot = reinterpret_cast<const uint32_t*>(&sh.queue[0][0])[r];
-      const uint32_t word = sh.keys[slot];
-      const unsigned long long q = sh.chg[slot];
-      sh.keys[slot] = EMPTY;
-      sh.chg[slot] = 0ull;
-      const uint32_t key = word & KEY_MASK;
-      const int pad = (int)(key & 0x3fffu), tb = (int)(key >> 14);
-      my_charge += q;
-      my_keys += (event << 24) + (unsigned long long)key;
-      if (base != ~0ull) {
-        const unsigned long long row = base + r;
-        double ua, ub;
-        rng_pair(a.seed, event, key, DOMAIN_JITTER, ua, ub);  // simulator.py:108
-        double* o = a.out.points + row * 3;
-        o[0] = (double)pad;
-        o[1] = (double)tb + ua;
-        o[2] = (double)q;
-        a.out.labels[row] = (int64_t)sh.label_of[word >> 24];  // from LDS: a global load here would
-                                                                // make every store wait (one vmcnt)
-      }
-    }
-    // no barrier here: the next window was published before the row stores, and the first barrier of
-    // its staging orders these LDS resets before any new insert while the sample loads of that
-    // staging overlap the store acknowledgements
-    PHASE_MARK(7);
   }
   PHASE_FLUSH;
 
-  // ---- per-event statistics ----
+  // ---- workgroup totals ----
   for (int off = 32; off > 0; off >>= 1) {
     my_charge += __shfl_down(my_charge, off);
     my_keys += __shfl_down(my_keys, off);
@@ -797,16 +846,25 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
   }
   __syncthreads();
   if (tid == 0) {
-    if (total) atomicAdd(&a.out.ctrl[7], (unsigned long long)total);
+    if (sh.wg_samples) atomicAdd(&a.out.ctrl[7], sh.wg_samples);
+    if (sh.wg_rows) atomicAdd(&a.out.ctrl[CTRL_ROWS], sh.wg_rows);
     if (sh.charge_sum) atomicAdd(&a.out.ctrl[2], sh.charge_sum);
     if (sh.key_sum) atomicAdd(&a.out.ctrl[3], sh.key_sum);
-    if (sh.failed) atomicAdd(&a.out.ctrl[4], 1ull);
+    if (sh.failed) atomicAdd(&a.out.ctrl[4], (unsigned long long)sh.failed);
     if (sh.retried) atomicAdd(&a.out.ctrl[5], (unsigned long long)sh.retried);
+    // reserved but unused segment slots read as empty segments
+    Segment none;
+    none.event = 0; none.count = 0; none.offset = 0;
+    for (unsigned long long g = sh.seg_cur; g < sh.seg_end && g < (unsigned long long)a.out.seg_capacity; ++g)
+      a.out.segments[g] = none;
   }
 }
 
-void launch_scatter_kernel(uint32_t n_events, hipStream_t s, const ScatterArgs& a) {
-  hipLaunchKernelGGL(scatter_kernel, dim3(n_events), dim3(SC_THREADS), 0, s, a);
+#undef tid
+#undef lane
+
+void launch_scatter_kernel(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a) {
+  hipLaunchKernelGGL(scatter_kernel, dim3(n_workgroups), dim3(SC_THREADS), 0, s, a);
 }
 
 }  // namespace attpc

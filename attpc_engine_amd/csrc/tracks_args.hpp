@@ -25,6 +25,8 @@ struct ScatterArgs {
   uint64_t seed;
   uint64_t first_event;
   uint32_t n_events;
+  uint32_t batch;      // events a workgroup takes per visit to the event counter
+  uint32_t row_block;  // output rows a workgroup reserves at a time (1: exactly what each window needs)
 };
 
 void launch_kin_run(hipStream_t s, const attpc_kin_desc& d, uint64_t seed, uint64_t first_event, uint32_t n,
@@ -34,7 +36,7 @@ void launch_kin_calculate(hipStream_t s, const attpc_kin_desc& d, uint32_t n, co
 void launch_decay_calculate(hipStream_t s, uint32_t n, const double* parent, double m1, double m2, const double* ex,
                             const double* th, const double* ph, double* out, int32_t* status);
 void launch_track_kernel(uint32_t blocks, size_t lds_bytes, hipStream_t s, const TrackArgs& a);
-void launch_scatter_kernel(uint32_t n_events, hipStream_t s, const ScatterArgs& a);
+void launch_scatter_kernel(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a);
 
 // response + threshold + Spyral rows on device (spyral.hip)
 struct SpyralDev {

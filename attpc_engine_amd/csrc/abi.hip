@@ -120,51 +120,31 @@ struct ChunkResult {
   float ms_tracks = 0, ms_scatter = 0;
 };
 
-// tracks + scatter for `n` events whose kinematics already sit in ctx->p4 / vertex (/status)
-int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64_t seed, uint64_t first_event,
-                           uint32_t n, bool use_status, ChunkResult* res) {
+// Track integration for a BATCH of `n` events whose kinematics already sit in ctx->p4 / vertex
+// (/status).  A batch spans several scatter chunks: the track kernel hands tracks to lanes
+// dynamically, and with fewer tracks than a few times the 200 k lanes of the chip the launch is one
+// generation of tracks whose length is set by its longest member.
+int32_t run_tracks(attpc_ctx* ctx, const attpc_event_layout& lay, uint64_t seed, uint64_t first_event, uint32_t n,
+                   bool use_status, TrackBuffers* out_buf, double* ms) {
   const uint32_t n_tracks = n * (uint32_t)lay.n_sim;
-  if (n_tracks == 0) {
-    *res = ChunkResult{};
-    return ATTPC_OK;
-  }
+  *out_buf = TrackBuffers{};
+  if (n_tracks == 0) return ATTPC_OK;
   int32_t rc;
   if ((rc = ensure(ctx, ctx->block_table, (size_t)n_tracks * MAX_BLOCKS_PER_TRACK * sizeof(int32_t)))) return rc;
   if ((rc = ensure(ctx, ctx->counts, (size_t)n_tracks * sizeof(int32_t)))) return rc;
   if ((rc = ensure(ctx, ctx->n_steps, (size_t)n_tracks * sizeof(int32_t)))) return rc;
   if ((rc = ensure(ctx, ctx->trk_ctrl, 16 * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->out_ctrl, 32 * sizeof(unsigned long long)))) return rc;
-  size_t want_blocks = std::max<size_t>(ctx->arena_blocks, (size_t)n_tracks * 6 + 1024);
-  // scatter launch geometry: persistent workgroups, one per compute unit, that take `batch` events per
-  // visit to the event counter and reserve output rows `row_block` at a time (small launches: batch
-  // 1 and exact reservations, so that short runs still spread over the chip and waste no rows)
-  const uint32_t sc_wgs = std::min<uint32_t>((uint32_t)ctx->n_cus, n);
-  const uint32_t sc_batch = std::max<uint32_t>(1u, std::min<uint32_t>(8u, n / (sc_wgs * 8u)));
-  const int64_t est_rows = (int64_t)n * 9216;
-  const uint32_t sc_row_block = est_rows / ((int64_t)sc_wgs * 16) >= 16384
-                                    ? (uint32_t)std::min<int64_t>(est_rows / ((int64_t)sc_wgs * 16), 1 << 18) : 1u;
-  const int64_t hole_rows = sc_row_block > 1u ? (int64_t)sc_wgs * sc_row_block + est_rows / 16 : 0;
-  int64_t want_rows = std::max<int64_t>(ctx->cloud_capacity, est_rows + hole_rows + 65536);
-  int64_t want_segs = std::max<int64_t>(ctx->seg_capacity, (int64_t)n * 6 + 4096 + (int64_t)sc_wgs * 16);
-  if (std::getenv("ATTPC_TEST_TINY_BUFFERS") && ctx->arena_blocks == 0) {
-    // test hook: start with buffers that are certainly too small so the grow-and-rerun path runs
-    want_blocks = 4;
-    want_rows = 64;
-    want_segs = 2;
-  }
+  const size_t lds = (size_t)ctx->det.n_species * ATTPC_DEDX_NODES * sizeof(double);
+  const uint32_t waves_needed = (n_tracks + 63) / 64;
+  const uint32_t blocks = std::min<uint32_t>((waves_needed + 3) / 4, (uint32_t)ctx->n_cus * 8u);
+  // every wave reserves arena blocks 64 at a time: that slack comes on top of what the samples need
+  size_t want_blocks = std::max<size_t>(ctx->arena_blocks, (size_t)n_tracks * 3 + (size_t)blocks * 4 * 64 + 1024);
+  if (std::getenv("ATTPC_TEST_TINY_BUFFERS") && ctx->arena_blocks == 0) want_blocks = 4;  // test hook: grow-and-rerun path
 
   for (int attempt = 0; attempt < 8; ++attempt) {
     if ((rc = ensure(ctx, ctx->arena, want_blocks * ARENA_BLK * 4 * sizeof(double)))) return rc;
     ctx->arena_blocks = want_blocks;
-    if ((rc = ensure(ctx, ctx->points, (size_t)want_rows * 3 * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->labels, (size_t)want_rows * sizeof(int64_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->segments, (size_t)want_segs * sizeof(Segment)))) return rc;
-    ctx->cloud_capacity = want_rows;
-    ctx->seg_capacity = want_segs;
-
     HIP_TRY(ctx, hipMemsetAsync(ctx->trk_ctrl.p, 0, 16 * sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->out_ctrl.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
-
     TrackArgs ta;
     ta.det = ctx->det;
     ta.layout = lay;
@@ -181,18 +161,62 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
     ta.first_event = first_event;
     ta.n_events = n;
     ta.n_tracks = n_tracks;
-    const size_t lds = (size_t)ctx->det.n_species * ATTPC_DEDX_NODES * sizeof(double);
-    const uint32_t waves_needed = (n_tracks + 63) / 64;
-    const uint32_t blocks = std::min<uint32_t>((waves_needed + 3) / 4, 256u * 8u);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     launch_track_kernel(blocks, lds, ctx->stream, ta);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    uint32_t tctrl[4];
+    HIP_TRY(ctx, hipMemcpyAsync(tctrl, ctx->trk_ctrl.p, sizeof tctrl, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms_t = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms_t, ctx->ev[0], ctx->ev[1]));
+    *ms += ms_t;  // timings of discarded attempts stay counted: they were spent
+    if (tctrl[2] == 0) {  // no sample was refused
+      *out_buf = ta.buf;
+      return ATTPC_OK;
+    }
+    want_blocks = std::max<size_t>((size_t)tctrl[1] + 1024, want_blocks * 2);  // arena exhausted
+  }
+  return fail(ctx, ATTPC_E_HIP, "track arena did not fit after repeated growth");
+}
 
+// Scatter for the `n` events starting at event `e0` of the current track batch (global id
+// `first_event` = batch first + e0).
+int32_t run_scatter(attpc_ctx* ctx, const attpc_event_layout& lay, const TrackBuffers& trk, uint64_t seed,
+                    uint64_t first_event, uint32_t e0, uint32_t n, ChunkResult* res) {
+  if (n == 0 || lay.n_sim == 0) {
+    *res = ChunkResult{};
+    return ATTPC_OK;
+  }
+  int32_t rc;
+  if ((rc = ensure(ctx, ctx->out_ctrl, 32 * sizeof(unsigned long long)))) return rc;
+  // launch geometry: persistent workgroups, one per compute unit, that take `batch` events per visit
+  // to the event counter and reserve output rows `row_block` at a time (small launches: batch 1 and
+  // exact reservations, so that short runs still spread over the chip and waste no rows)
+  const uint32_t sc_wgs = std::min<uint32_t>((uint32_t)ctx->n_cus, n);
+  const uint32_t sc_batch = std::max<uint32_t>(1u, std::min<uint32_t>(8u, n / (sc_wgs * 8u)));
+  const int64_t est_rows = (int64_t)n * 9216;
+  const uint32_t sc_row_block = est_rows / ((int64_t)sc_wgs * 16) >= 16384
+                                    ? (uint32_t)std::min<int64_t>(est_rows / ((int64_t)sc_wgs * 16), 1 << 18) : 1u;
+  const int64_t hole_rows = sc_row_block > 1u ? (int64_t)sc_wgs * sc_row_block + est_rows / 16 : 0;
+  int64_t want_rows = std::max<int64_t>(ctx->cloud_capacity, est_rows + hole_rows + 65536);
+  int64_t want_segs = std::max<int64_t>(ctx->seg_capacity, (int64_t)n * 6 + 4096 + (int64_t)sc_wgs * 16);
+  if (std::getenv("ATTPC_TEST_TINY_BUFFERS") && ctx->cloud_capacity == 0) {
+    want_rows = 64;  // test hook: start with buffers that are certainly too small
+    want_segs = 2;
+  }
+
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    if ((rc = ensure(ctx, ctx->points, (size_t)want_rows * 3 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->labels, (size_t)want_rows * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->segments, (size_t)want_segs * sizeof(Segment)))) return rc;
+    ctx->cloud_capacity = want_rows;
+    ctx->seg_capacity = want_segs;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->out_ctrl.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
     ScatterArgs sa;
     sa.det = ctx->det;
     sa.layout = lay;
-    sa.trk = ta.buf;
+    sa.trk = trk;
     sa.out.points = static_cast<double*>(ctx->points.p);
     sa.out.labels = static_cast<int64_t*>(ctx->labels.p);
     sa.out.segments = static_cast<Segment*>(ctx->segments.p);
@@ -202,34 +226,19 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
     sa.seed = seed;
     sa.first_event = first_event;
     sa.n_events = n;
+    sa.event0 = e0;
     sa.batch = sc_batch;
     sa.row_block = sc_row_block;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     launch_scatter_kernel(sc_wgs, ctx->stream, sa);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-
-    uint32_t tctrl[4];
     unsigned long long octrl[32];
-    HIP_TRY(ctx, hipMemcpyAsync(tctrl, ctx->trk_ctrl.p, sizeof tctrl, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(octrl, ctx->out_ctrl.p, sizeof octrl, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    float ms_t = 0, ms_s = 0;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms_t, ctx->ev[0], ctx->ev[1]));
+    float ms_s = 0;
     HIP_TRY(ctx, hipEventElapsedTime(&ms_s, ctx->ev[2], ctx->ev[3]));
-    res->ms_tracks += ms_t;
     res->ms_scatter += ms_s;
-
-    bool retry = false;
-    if (tctrl[2] != 0 || tctrl[1] > want_blocks) {  // arena exhausted
-      want_blocks = std::max<size_t>((size_t)tctrl[1] + 1024, want_blocks * 2);
-      retry = true;
-    }
-    if (octrl[6] != 0) {  // cloud / segment capacity exceeded (cursors kept counting)
-      want_rows = std::max<int64_t>(want_rows, (int64_t)(octrl[0] + octrl[0] / 8) + 65536);
-      want_segs = std::max<int64_t>(want_segs, (int64_t)(octrl[1] + octrl[1] / 8) + 4096);
-      retry = true;
-    }
 #ifdef ATTPC_PHASE_TIMERS
     fprintf(stderr, "[attpc phase cycles] init %llu hist %llu select %llu stage %llu items %llu overflow %llu flushcount %llu flushwrite %llu (events %u)\n",
             octrl[8], octrl[9], octrl[10], octrl[11], octrl[12], octrl[13], octrl[14], octrl[15], n);
@@ -239,7 +248,7 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
     fprintf(stderr, "[attpc ctrl] rows %llu segments %llu failed %llu retried %llu samples %llu\n", octrl[0], octrl[1],
             octrl[4], octrl[5], octrl[7]);
 #endif
-    if (!retry) {
+    if (octrl[6] == 0) {
       res->rows = octrl[30];  // rows written; octrl[0] is the reservation cursor (holes included)
       res->segs = octrl[1];
       res->charge = octrl[2];
@@ -249,9 +258,19 @@ int32_t run_detector_chunk(attpc_ctx* ctx, const attpc_event_layout& lay, uint64
       res->samples = octrl[7];
       return ATTPC_OK;
     }
-    res->ms_tracks -= 0;  // timings of discarded attempts stay counted: they were spent
+    // cloud / segment capacity exceeded (the cursors kept counting)
+    want_rows = std::max<int64_t>(want_rows, (int64_t)(octrl[0] + octrl[0] / 8) + 65536);
+    want_segs = std::max<int64_t>(want_segs, (int64_t)(octrl[1] + octrl[1] / 8) + 4096);
   }
-  return fail(ctx, ATTPC_E_HIP, "detector chunk did not fit after repeated buffer growth");
+  return fail(ctx, ATTPC_E_HIP, "point cloud did not fit after repeated buffer growth");
+}
+
+// events per track batch: several scatter chunks, bounded so that the sample arena stays below ~24 GB
+uint64_t track_batch_events(const attpc_ctx* ctx, const attpc_event_layout& lay) {
+  const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events);
+  const uint64_t by_memory = (24ull << 30) / ((uint64_t)std::max(1, lay.n_sim) * 3ull * ARENA_BLK * 4 * sizeof(double));
+  const uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>(8, by_memory / chunk));
+  return chunk * chunks;
 }
 
 // Device-side CSR assembly: segment s (one flushed window of one event) is copied to row
@@ -632,9 +651,7 @@ static void accumulate(attpc_run_stats* st, const ChunkResult& r) {
   st->n_lds_overflow += r.retried;
   st->charge_checksum += r.charge;
   st->key_checksum += r.keys;
-  st->ms_tracks += r.ms_tracks;
   st->ms_scatter += r.ms_scatter;
-  st->launches_tracks += 1;
   st->launches_scatter += 1;
 }
 
@@ -650,18 +667,25 @@ int32_t attpc_det_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint6
   st.n_events = n_events;
   const int n_rows = layout->n_rows;
   const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events);
+  const uint64_t batch = track_batch_events(ctx, *layout);
   int64_t row_cursor = 0;
   bool over = false;
   if (out && out->offsets) out->offsets[0] = 0;
-  for (uint64_t done = 0; done < n_events; done += chunk) {
-    const uint32_t n = (uint32_t)std::min<uint64_t>(chunk, n_events - done);
-    if ((rc = ensure_kin_buffers(ctx, n, n_rows))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->p4.p, p4 + done * n_rows * 4, (size_t)n * n_rows * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->vertex.p, vertex + done * 3, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    ChunkResult r;
-    if ((rc = run_detector_chunk(ctx, *layout, seed, first_event + done, n, false, &r))) return rc;
-    accumulate(&st, r);
-    if (out && (rc = assemble_chunk(ctx, r, n, done, out, &row_cursor, &over))) return rc;
+  for (uint64_t b0 = 0; b0 < n_events; b0 += batch) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(batch, n_events - b0);
+    if ((rc = ensure_kin_buffers(ctx, nb, n_rows))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->p4.p, p4 + b0 * n_rows * 4, (size_t)nb * n_rows * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->vertex.p, vertex + b0 * 3, (size_t)nb * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TrackBuffers trk;
+    if ((rc = run_tracks(ctx, *layout, seed, first_event + b0, nb, false, &trk, &st.ms_tracks))) return rc;
+    st.launches_tracks += 1;
+    for (uint32_t e0 = 0; e0 < nb; e0 += (uint32_t)chunk) {
+      const uint32_t n = (uint32_t)std::min<uint64_t>(chunk, nb - e0);
+      ChunkResult r;
+      if ((rc = run_scatter(ctx, *layout, trk, seed, first_event + b0 + e0, e0, n, &r))) return rc;
+      accumulate(&st, r);
+      if (out && (rc = assemble_chunk(ctx, r, n, b0 + e0, out, &row_cursor, &over))) return rc;
+    }
   }
   if (stats) *stats = st;
   if (over) return fail(ctx, ATTPC_E_CAPACITY, "cloud needs %lld rows, capacity %lld", (long long)row_cursor, (long long)out->capacity);
@@ -683,36 +707,43 @@ static int32_t sim_run_impl(attpc_ctx* ctx, uint64_t seed, uint64_t first_event,
   attpc_run_stats st{};
   st.n_events = n_events;
   const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events);
+  const uint64_t batch = track_batch_events(ctx, *layout);
   int64_t row_cursor = 0;
   bool over = false;
   if (out && out->offsets) out->offsets[0] = 0;
   std::vector<int32_t> hstatus;
-  for (uint64_t done = 0; done < n_events; done += chunk) {
-    const uint32_t n = (uint32_t)std::min<uint64_t>(chunk, n_events - done);
-    if ((rc = ensure_kin_buffers(ctx, n, n_rows))) return rc;
+  for (uint64_t b0 = 0; b0 < n_events; b0 += batch) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(batch, n_events - b0);
+    if ((rc = ensure_kin_buffers(ctx, nb, n_rows))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    launch_kin_run(ctx->stream, ctx->kin, seed, first_event + done, n, static_cast<double*>(ctx->p4.p),
+    launch_kin_run(ctx->stream, ctx->kin, seed, first_event + b0, nb, static_cast<double*>(ctx->p4.p),
                    static_cast<double*>(ctx->vertex.p), static_cast<int32_t*>(ctx->status.p),
                    static_cast<uint32_t*>(ctx->attempts.p));
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-    ChunkResult r;
-    if ((rc = run_detector_chunk(ctx, *layout, seed, first_event + done, n, true, &r))) return rc;
+    TrackBuffers trk;
+    if ((rc = run_tracks(ctx, *layout, seed, first_event + b0, nb, true, &trk, &st.ms_tracks))) return rc;
     float ms_k = 0;
     HIP_TRY(ctx, hipEventElapsedTime(&ms_k, ctx->ev[4], ctx->ev[5]));
     st.ms_kinematics += ms_k;
     st.launches_kinematics += 1;
-    accumulate(&st, r);
-    hstatus.resize(n);
-    HIP_TRY(ctx, hipMemcpy(hstatus.data(), ctx->status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    st.launches_tracks += 1;
+    hstatus.resize(nb);
+    HIP_TRY(ctx, hipMemcpy(hstatus.data(), ctx->status.p, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int32_t s : hstatus) st.n_sample_limit += (s != 0);
-    if (kin_status) std::memcpy(kin_status + done, hstatus.data(), (size_t)n * sizeof(int32_t));
-    if (p4) HIP_TRY(ctx, hipMemcpy(p4 + done * n_rows * 4, ctx->p4.p, (size_t)n * n_rows * 4 * sizeof(double), hipMemcpyDeviceToHost));
-    if (vertex) HIP_TRY(ctx, hipMemcpy(vertex + done * 3, ctx->vertex.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    if (out) {
-      rc = spyral ? assemble_chunk_spyral(ctx, r, n, done, out, &row_cursor, &over)
-                  : assemble_chunk(ctx, r, n, done, out, &row_cursor, &over);
-      if (rc) return rc;
+    if (kin_status) std::memcpy(kin_status + b0, hstatus.data(), (size_t)nb * sizeof(int32_t));
+    if (p4) HIP_TRY(ctx, hipMemcpy(p4 + b0 * n_rows * 4, ctx->p4.p, (size_t)nb * n_rows * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    if (vertex) HIP_TRY(ctx, hipMemcpy(vertex + b0 * 3, ctx->vertex.p, (size_t)nb * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    for (uint32_t e0 = 0; e0 < nb; e0 += (uint32_t)chunk) {
+      const uint32_t n = (uint32_t)std::min<uint64_t>(chunk, nb - e0);
+      ChunkResult r;
+      if ((rc = run_scatter(ctx, *layout, trk, seed, first_event + b0 + e0, e0, n, &r))) return rc;
+      accumulate(&st, r);
+      if (out) {
+        rc = spyral ? assemble_chunk_spyral(ctx, r, n, b0 + e0, out, &row_cursor, &over)
+                    : assemble_chunk(ctx, r, n, b0 + e0, out, &row_cursor, &over);
+        if (rc) return rc;
+      }
     }
   }
   if (spyral) st.n_points = (uint64_t)row_cursor;  // rows that survive the threshold
@@ -778,8 +809,9 @@ int32_t attpc_det_tracks(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, ui
   if ((rc = ensure_kin_buffers(ctx, n, n_rows))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->p4.p, p4, (size_t)n * n_rows * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->vertex.p, vertex, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  ChunkResult r;
-  if ((rc = run_detector_chunk(ctx, *layout, seed, first_event, n, false, &r))) return rc;
+  TrackBuffers trk;
+  double ms = 0;
+  if ((rc = run_tracks(ctx, *layout, seed, first_event, n, false, &trk, &ms))) return rc;
   const uint32_t n_tracks = n * (uint32_t)layout->n_sim;
   uint32_t tctrl[4];
   HIP_TRY(ctx, hipMemcpy(tctrl, ctx->trk_ctrl.p, sizeof tctrl, hipMemcpyDeviceToHost));
@@ -788,7 +820,8 @@ int32_t attpc_det_tracks(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, ui
   HIP_TRY(ctx, hipMemcpy(counts, ctx->counts.p, (size_t)n_tracks * sizeof(int32_t), hipMemcpyDeviceToHost));
   HIP_TRY(ctx, hipMemcpy(n_steps, ctx->n_steps.p, (size_t)n_tracks * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (samples) {
-    std::vector<double> arena((size_t)tctrl[1] * ARENA_BLK * 4);
+    // tctrl[1] counts reserved blocks (waves reserve pools), all below arena_blocks after a good run
+    std::vector<double> arena(std::min<size_t>(tctrl[1], ctx->arena_blocks) * ARENA_BLK * 4);
     if (!arena.empty()) HIP_TRY(ctx, hipMemcpy(arena.data(), ctx->arena.p, arena.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (uint32_t t = 0; t < n_tracks; ++t) {
       const int64_t c = std::min<int64_t>(counts[t], max_samples_per_track);

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
     for (uint32_t e_local = batch_first; e_local < batch_end; ++e_local) {
       if (e_local != batch_first) __syncthreads();
       const uint64_t event = a.first_event + e_local;
-      const uint32_t track0 = e_local * (uint32_t)n_sim;
+      const uint32_t track0 = (a.event0 + e_local) * (uint32_t)n_sim;
       // ---- per-event init ----
       for (int i = tid; i < ATTPC_NUM_TB; i += SC_THREADS) {
         sh.cum[i] = 0ull;

@@ -28,6 +28,9 @@ namespace attpc {
 #endif
 constexpr int TRACK_THREADS = ATTPC_TRACK_THREADS;
 constexpr int STEPS_PER_REFILL = ATTPC_TRACK_REFILL;  // steps between two looks for finished lanes
+constexpr int TRACK_ID_BATCH = 128;   // track ids a wave takes from the global counter at a time
+constexpr int BLOCK_POOL = 64;        // arena blocks a wave reserves at a time (>= 64: one request can need a block per lane)
+static_assert(TRACK_ID_BATCH >= 64 && BLOCK_POOL >= 64, "a single request can be one per lane");
 
 
 struct Decomp {  // |gamma*beta| decomposition of a state, shared by the RHS and the event tests
@@ -91,17 +94,35 @@ __global__ __launch_bounds__(TRACK_THREADS) void track_kernel(TrackArgs a) {
   const double* tab = lds_tab;
   double z_cache = 0.0;   // second Box-Muller normal of the cached Philox call
   int z_cache_idx = -1;
+  uint32_t ids_next = 0, ids_end = 0;    // this wave's batch of track ids (wave uniform)
+  uint32_t pool_next = 0, pool_end = 0;  // this wave's reserved arena blocks (wave uniform)
 
   for (;;) {
+    // next track ids: the wave takes them from its own batch and refills the batch from the global
+    // counter TRACK_ID_BATCH at a time (a returning atomic on one hot address costs microseconds;
+    // once per finished track it dominated this kernel)
+    const unsigned long long need = __ballot(!active && !retired);  // wave uniform from here ...
+    uint32_t next_id = 0;
+    if (need) {
+      const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+      const uint32_t want = (uint32_t)__popcll(need);
+      if (ids_next + want > ids_end) {
+        // ids left in the old batch are handed out first, the rest come from the new one
+        const uint32_t left = ids_end - ids_next;
+        const int leader = __ffsll((long long)need) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&a.buf.ctrl[0], (uint32_t)TRACK_ID_BATCH);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        next_id = rank < left ? ids_next + rank : base + (rank - left);
+        ids_next = base + (want - left);
+        ids_end = base + (uint32_t)TRACK_ID_BATCH;
+      } else {
+        next_id = ids_next + rank;
+        ids_next += want;
+      }
+    }  // ... to here
     if (!active && !retired) {
-      // wave-aggregated pull of the next track ids
-      const unsigned long long need = __ballot(1);
-      const int leader = __ffsll((long long)need) - 1;
-      const int rank = __popcll(need & ((1ull << lane) - 1ull));
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&a.buf.ctrl[0], (uint32_t)__popcll(need));
-      base = __shfl(base, leader);
-      tid = base + (uint32_t)rank;
+      tid = next_id;
       if (tid >= a.n_tracks) {
         retired = true;
       } else {
@@ -151,84 +172,108 @@ __global__ __launch_bounds__(TRACK_THREADS) void track_kernel(TrackArgs a) {
     if (__all(retired)) break;
 
     for (int it = 0; it < STEPS_PER_REFILL; ++it) {
-      if (!active) continue;
       bool stop = false;
-      for (int sub = 0; sub < nsub && !stop; ++sub) {
-        double k1[6], k2[6], k3[6], k4[6], y[6];
-        rhs(s, dc, sc, tab, k1);
+      long long n_el = 0;
+      if (active) {
+        for (int sub = 0; sub < nsub && !stop; ++sub) {
+          double k1[6], k2[6], k3[6], k4[6], y[6];
+          rhs(s, dc, sc, tab, k1);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) y[i] = s[i] + 0.5 * h * k1[i];
-        Decomp d2 = decompose(y[3], y[4], y[5], sc.mass);
-        rhs(y, d2, sc, tab, k2);
+          for (int i = 0; i < 6; ++i) y[i] = s[i] + 0.5 * h * k1[i];
+          Decomp d2 = decompose(y[3], y[4], y[5], sc.mass);
+          rhs(y, d2, sc, tab, k2);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) y[i] = s[i] + 0.5 * h * k2[i];
-        d2 = decompose(y[3], y[4], y[5], sc.mass);
-        rhs(y, d2, sc, tab, k3);
+          for (int i = 0; i < 6; ++i) y[i] = s[i] + 0.5 * h * k2[i];
+          d2 = decompose(y[3], y[4], y[5], sc.mass);
+          rhs(y, d2, sc, tab, k3);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) y[i] = s[i] + h * k3[i];
-        d2 = decompose(y[3], y[4], y[5], sc.mass);
-        rhs(y, d2, sc, tab, k4);
+          for (int i = 0; i < 6; ++i) y[i] = s[i] + h * k3[i];
+          d2 = decompose(y[3], y[4], y[5], sc.mass);
+          rhs(y, d2, sc, tab, k4);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s[i] = s[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
-        dc = decompose(s[3], s[4], s[5], sc.mass);
-        // terminal events with scipy's sign-change test (solver.py:80-240, :276-283)
-        const double n_ke = dc.ke - KE_LIMIT;
-        const double n_zf = s[2] - 1.0;
-        const double n_zb = s[2];
-        const double n_rho = s[0] * s[0] + s[1] * s[1] - RHO_MAX * RHO_MAX;
-        stop = (g_ke >= 0.0 && n_ke <= 0.0) || (g_zf <= 0.0 && n_zf >= 0.0) ||
-               (g_zb >= 0.0 && n_zb <= 0.0) || (g_rho <= 0.0 && n_rho >= 0.0) || !(n_ke == n_ke);
-        g_ke = n_ke; g_zf = n_zf; g_zb = n_zb; g_rho = n_rho;
-      }
-      if (!stop) {
-        k++;
-        // generate_electrons, solver.py:338-346: mu = |dKE| 1e6 / W, n = trunc(N(mu, sqrt(F mu)))
-        const double mu = fabs(dc.ke - ke_prev) * e_scale;
-        ke_prev = dc.ke;
-        const double sig = sqrt(a.det.fano_factor * mu);
-        long long n_el = 0;
-        if (mu + 9.0 * sig >= 1.0) {  // |z| <= 8.6 for a 53-bit uniform: otherwise n = 0 for certain
-          double z;
-          if (z_cache_idx == (k >> 1) && (k & 1)) {
-            z = z_cache;
-          } else {
-            double ua, ub;
-            rng_pair(a.seed, event, (uint32_t)(k >> 1), fano_domain, ua, ub);
-            const double rad = sqrt(-2.0 * log(1.0 - ua));
-            double sn, cs;
-            sincos(TWO_PI * ub, &sn, &cs);
-            z = (k & 1) ? rad * sn : rad * cs;
-            z_cache = rad * sn;
-            z_cache_idx = k >> 1;
-          }
-          n_el = (long long)(mu + sig * z);
+          for (int i = 0; i < 6; ++i) s[i] = s[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+          dc = decompose(s[3], s[4], s[5], sc.mass);
+          // terminal events with scipy's sign-change test (solver.py:80-240, :276-283)
+          const double n_ke = dc.ke - KE_LIMIT;
+          const double n_zf = s[2] - 1.0;
+          const double n_zb = s[2];
+          const double n_rho = s[0] * s[0] + s[1] * s[1] - RHO_MAX * RHO_MAX;
+          stop = (g_ke >= 0.0 && n_ke <= 0.0) || (g_zf <= 0.0 && n_zf >= 0.0) ||
+                 (g_zb >= 0.0 && n_zb <= 0.0) || (g_rho <= 0.0 && n_rho >= 0.0) || !(n_ke == n_ke);
+          g_ke = n_ke; g_zf = n_zf; g_zb = n_zb; g_rho = n_rho;
         }
-        if (n_el >= 1) {  // solver.py:387-392
-          const int slot = count & (ARENA_BLK - 1);
-          if (slot == 0) {
-            const uint32_t blk = atomicAdd(&a.buf.ctrl[1], 1u);
-            if (blk < a.buf.arena_blocks) {
-              blk_ptr = a.buf.arena + (size_t)blk * ARENA_BLK * 4;
-              a.buf.block_table[(size_t)tid * MAX_BLOCKS_PER_TRACK + (count / ARENA_BLK)] = (int32_t)blk;
+        if (!stop) {
+          k++;
+          // generate_electrons, solver.py:338-346: mu = |dKE| 1e6 / W, n = trunc(N(mu, sqrt(F mu)))
+          const double mu = fabs(dc.ke - ke_prev) * e_scale;
+          ke_prev = dc.ke;
+          const double sig = sqrt(a.det.fano_factor * mu);
+          if (mu + 9.0 * sig >= 1.0) {  // |z| <= 8.6 for a 53-bit uniform: otherwise n = 0 for certain
+            double z;
+            if (z_cache_idx == (k >> 1) && (k & 1)) {
+              z = z_cache;
             } else {
-              blk_ptr = nullptr;
-              a.buf.ctrl[2] = 1u;  // arena exhausted: host re-runs the chunk with a larger arena
+              double ua, ub;
+              rng_pair(a.seed, event, (uint32_t)(k >> 1), fano_domain, ua, ub);
+              const double rad = sqrt(-2.0 * log(1.0 - ua));
+              double sn, cs;
+              sincos(TWO_PI * ub, &sn, &cs);
+              z = (k & 1) ? rad * sn : rad * cs;
+              z_cache = rad * sn;
+              z_cache_idx = k >> 1;
             }
-          }
-          if (blk_ptr != nullptr) {
-            double* o = blk_ptr + slot * 4;
-            const double tb = (a.det.length - s[2]) * a.det.inv_dv + a.det.mm_edge;  // solver.py:395-398
-            reinterpret_cast<double2*>(o)[0] = make_double2(s[0], s[1]);
-            reinterpret_cast<double2*>(o)[1] = make_double2(tb, (double)(n_el * a.det.mpgd_gain));
-            count++;
+            n_el = (long long)(mu + sig * z);
           }
         }
-        if (k >= ATTPC_TIME_SAMPLES - 1) stop = true;  // t = 1 us: last recorded sample
       }
-      if (stop) {
-        a.buf.counts[tid] = count;
-        a.buf.n_steps[tid] = k + 1;
-        active = false;
+      // arena blocks for the lanes that start a new block, from the wave's reserved pool (wave uniform:
+      // one global atomic per BLOCK_POOL blocks instead of one per block)
+      const bool new_blk = n_el >= 1 && (count & (ARENA_BLK - 1)) == 0;
+      const unsigned long long blk_mask = __ballot(new_blk);
+      uint32_t blk = 0;
+      if (blk_mask) {
+        const uint32_t rank = (uint32_t)__popcll(blk_mask & ((1ull << lane) - 1ull));
+        const uint32_t want = (uint32_t)__popcll(blk_mask);
+        if (pool_next + want > pool_end) {
+          const uint32_t left = pool_end - pool_next;
+          const int leader = __ffsll((long long)blk_mask) - 1;
+          uint32_t base = 0;
+          if (lane == leader) base = atomicAdd(&a.buf.ctrl[1], (uint32_t)BLOCK_POOL);
+          base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+          blk = rank < left ? pool_next + rank : base + (rank - left);
+          pool_next = base + (want - left);
+          pool_end = base + (uint32_t)BLOCK_POOL;
+        } else {
+          blk = pool_next + rank;
+          pool_next += want;
+        }
+      }
+      if (n_el >= 1) {  // solver.py:387-392
+        const int slot = count & (ARENA_BLK - 1);
+        if (new_blk) {
+          if (blk < a.buf.arena_blocks) {
+            blk_ptr = a.buf.arena + (size_t)blk * ARENA_BLK * 4;
+            a.buf.block_table[(size_t)tid * MAX_BLOCKS_PER_TRACK + (count / ARENA_BLK)] = (int32_t)blk;
+          } else {
+            blk_ptr = nullptr;
+            a.buf.ctrl[2] = 1u;  // arena exhausted: host re-runs the chunk with a larger arena
+          }
+        }
+        if (blk_ptr != nullptr) {
+          double* o = blk_ptr + slot * 4;
+          const double tb = (a.det.length - s[2]) * a.det.inv_dv + a.det.mm_edge;  // solver.py:395-398
+          reinterpret_cast<double2*>(o)[0] = make_double2(s[0], s[1]);
+          reinterpret_cast<double2*>(o)[1] = make_double2(tb, (double)(n_el * a.det.mpgd_gain));
+          count++;
+        }
+      }
+      if (active) {
+        if (!stop && k >= ATTPC_TIME_SAMPLES - 1) stop = true;  // t = 1 us: last recorded sample
+        if (stop) {
+          a.buf.counts[tid] = count;
+          a.buf.n_steps[tid] = k + 1;
+          active = false;
+        }
       }
     }
   }

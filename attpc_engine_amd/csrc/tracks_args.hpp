@@ -25,6 +25,7 @@ struct ScatterArgs {
   uint64_t seed;
   uint64_t first_event;
   uint32_t n_events;
+  uint32_t event0;     // first event of this launch within the track batch (track ids start at event0 * n_sim)
   uint32_t batch;      // events a workgroup takes per visit to the event counter
   uint32_t row_block;  // output rows a workgroup reserves at a time (1: exactly what each window needs)
 };

@@ -22,7 +22,7 @@ def child(workloads_csv: str, n: int) -> None:
     out = {}
     for name in workloads_csv.split(","):
         pipe, cfg, idx = workloads.WORKLOADS[name]()
-        eng = Engine(pipe, cfg, idx, context=ctx)
+        eng = Engine(pipe, cfg, idx, context=ctx, chunk_events=int(os.environ.get("ATTPC_AB_CHUNK", "0")) or None)
         eng.run(min(n, 20000), seed=1)
         ctx.lib.attpc_sync(ctx.handle)
         t0 = time.perf_counter()

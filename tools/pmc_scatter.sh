@@ -25,10 +25,12 @@ out, n = sys.argv[1], int(sys.argv[2])
 acc = collections.OrderedDict()
 for f in sorted(glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
-        if "scatter_kernel" in row["Kernel_Name"]:
-            acc[row["Counter_Name"]] = acc.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        for kern in ("scatter_kernel", "track_kernel"):
+            if kern in row["Kernel_Name"]:
+                key = kern + " " + row["Counter_Name"]
+                acc[key] = acc.get(key, 0.0) + float(row["Counter_Value"])
 with open(out + "/summary.txt", "w") as fh:
     for k, v in acc.items():
-        line = f"{k:32s} {v / n:14.1f} per event"
+        line = f"{k:48s} {v / n:14.1f} per event"
         print(line); fh.write(line + "\n")
 PY

@@ -165,15 +165,24 @@ __device__ __forceinline__ void clear_table(ScatterShared& sh) {
 }
 
 // first index in [lo, hi) whose prefix sum exceeds value; HIGH selects the entry count (high word)
-// instead of the estimated keys (low word)
+// instead of the estimated keys (low word).  Executed by one whole wave (ln = lane): a 64-way
+// search step over every 8th entry and an 8-way step inside the block found -- two LDS round trips
+// instead of the nine of a binary search (the selection sits on the workgroup's critical path).
+static_assert(ATTPC_NUM_TB == 64 * 8, "wave_upper_bound covers 8 buckets per lane");
 template <bool HIGH>
-__device__ __forceinline__ int upper_bound(const unsigned long long* cum, int lo, int hi, unsigned int value) {
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    const unsigned int v = HIGH ? (unsigned int)(cum[mid] >> 32) : (unsigned int)cum[mid];
-    if (v > value) hi = mid; else lo = mid + 1;
-  }
-  return lo;
+__device__ __forceinline__ int wave_upper_bound(const unsigned long long* cum, int lo, int hi, unsigned int value,
+                                                int ln) {
+  const int ic = ln * 8 + 7;
+  const unsigned long long vc = cum[ic];
+  const unsigned int fc = HIGH ? (unsigned int)(vc >> 32) : (unsigned int)vc;
+  const unsigned long long mc = __ballot(ic >= hi || (ic >= lo && fc > value));
+  if (mc == 0ull) return hi;
+  const int blk = __ffsll((long long)mc) - 1;
+  const int jf = blk * 8 + (ln & 7);
+  const unsigned long long vf = cum[jf];
+  const unsigned int ff = HIGH ? (unsigned int)(vf >> 32) : (unsigned int)vf;
+  const unsigned long long mf = __ballot(jf >= hi || (jf >= lo && ff > value)) & 0xffull;
+  return blk * 8 + (__ffsll((long long)mf) - 1);
 }
 
 constexpr int BUCKET = 4;                           // keys per bucket = one ds_read_b128
@@ -270,28 +279,39 @@ __device__ __forceinline__ bool wave_insert(ScatterShared& sh, uint32_t want, ui
 // extends while the estimated key count stays within the budget (at least one bucket).  A window
 // that does not reach the end of the event is then cut back to a whole number of row passes: the
 // rows phase works in passes of SC_THREADS mesh rows (64 per wave), a window of 2.2 passes costs 3,
-// so the 0.2 is left to the next window.  Thread 0.
-__device__ __forceinline__ void select_window(ScatterShared& sh, int from) {
+// so the 0.2 is left to the next window.  Wave 0 (every lane with the same arguments).
+__device__ __forceinline__ void select_window(ScatterShared& sh, int from, int budget, int ln) {
   const unsigned long long before = from > 0 ? sh.cum[from - 1] : 0ull;
   const unsigned int keys0 = (unsigned int)before, entries0 = (unsigned int)(before >> 32);
-  const int a0 = upper_bound<true>(sh.cum, from, ATTPC_NUM_TB, entries0);
+  const int a0 = wave_upper_bound<true>(sh.cum, from, ATTPC_NUM_TB, entries0, ln);
   if (a0 >= ATTPC_NUM_TB) {
-    sh.done = 1;
+    if (ln == 0) sh.done = 1;
     return;
   }
-  int b0 = upper_bound<false>(sh.cum, a0, ATTPC_NUM_TB, keys0 + (unsigned int)sh.budget);
+  int b0 = wave_upper_bound<false>(sh.cum, a0, ATTPC_NUM_TB, keys0 + (unsigned int)budget, ln);
   if (b0 <= a0) b0 = a0 + 1;
   const unsigned int entries = (unsigned int)(sh.cum[b0 - 1] >> 32) - entries0;
   const unsigned int passes = entries * MESH / SC_THREADS;
   if (passes >= 1u && (unsigned int)(sh.cum[ATTPC_NUM_TB - 1] >> 32) > entries0 + entries) {
-    const int b1 = upper_bound<true>(sh.cum, a0, b0, entries0 + passes * SC_THREADS / MESH);
+    const int b1 = wave_upper_bound<true>(sh.cum, a0, b0, entries0 + passes * SC_THREADS / MESH, ln);
     if (b1 > a0) b0 = b1;
   }
-  sh.win_a = a0;
-  sh.win_b = b0;
-  sh.win_samples = (int)((unsigned int)sh.cum[b0 - 1] - keys0);
-  sh.win_r0 = (int)entries0;  // the buckets between `from` and a0 are empty
-  sh.win_n = (int)((unsigned int)(sh.cum[b0 - 1] >> 32) - entries0);
+  if (ln == 0) {
+    const unsigned long long last = sh.cum[b0 - 1];
+    sh.budget = budget;
+    sh.win_a = a0;
+    sh.win_b = b0;
+    sh.win_samples = (int)((unsigned int)last - keys0);
+    sh.win_r0 = (int)entries0;  // the buckets between `from` and a0 are empty
+    sh.win_n = (int)((unsigned int)(last >> 32) - entries0);
+  }
+}
+
+// a wave-uniform constant the compiler may not hoist out of its loop (hoisted copies of such
+// constants ended up in VGPRs that were then spilled to scratch)
+__device__ __forceinline__ int local_const(int value) {
+  asm volatile("" : "+s"(value));
+  return value;
 }
 
 __device__ __forceinline__ int fresh_tid() {
@@ -356,17 +376,19 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
           acc += a.trk.counts[track0 + k];
         }
         for (int k = n_sim; k <= ATTPC_MAX_SIM; ++k) sh.cnt[k] = acc;
-        sh.win_a = 0; sh.win_b = 0; sh.budget = TARGET_KEYS; sh.overflow = 0; sh.done = 0; sh.ev_failed = 0;
+        const int zero = local_const(0);
+        sh.win_a = zero; sh.win_b = zero; sh.budget = local_const(TARGET_KEYS); sh.overflow = zero; sh.done = zero;
+        sh.ev_failed = zero;
         sh.wg_samples += (unsigned long long)acc;
+      }
+      // the arena block ids of the event's tracks, loaded together with the counts (entries past a
+      // track's last block are never used)
+      for (int i = tid; i < n_sim * MAX_BLOCKS_PER_TRACK; i += SC_THREADS) {
+        const int k = i / MAX_BLOCKS_PER_TRACK, b = i - k * MAX_BLOCKS_PER_TRACK;
+        sh.blocks[k][b] = a.trk.block_table[(size_t)(track0 + k) * MAX_BLOCKS_PER_TRACK + b];
       }
       __syncthreads();
       const int total = sh.cnt[ATTPC_MAX_SIM];
-      for (int i = tid; i < n_sim * MAX_BLOCKS_PER_TRACK; i += SC_THREADS) {
-        const int k = i / MAX_BLOCKS_PER_TRACK, b = i - k * MAX_BLOCKS_PER_TRACK;
-        const int n_blk = (sh.cnt[k + 1] - sh.cnt[k] + ARENA_BLK - 1) / ARENA_BLK;
-        sh.blocks[k][b] = b < n_blk ? a.trk.block_table[(size_t)(track0 + k) * MAX_BLOCKS_PER_TRACK + b] : 0;
-      }
-      __syncthreads();
       PHASE_MARK(0);
 
       // ---- histogram of kept samples per time bucket (all nuclei), then its prefix sum ----
@@ -431,7 +453,7 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
         const unsigned int before = my_tb > 0 ? (unsigned int)(sh.cum[my_tb - 1] >> 32) : 0u;
         sh.perm[before + atomicAdd(&reinterpret_cast<uint32_t*>(&sh.st_ix[0][0])[my_tb], 1u)] = (unsigned short)tid;
       }
-      if (tid == 0) select_window(sh, 0);
+      if (tid < 64) select_window(sh, 0, local_const(TARGET_KEYS), lane);
       __syncthreads();
       PHASE_MARK(1);
 
@@ -697,21 +719,19 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
         if (sh.overflow) {
           __syncthreads();
           clear_table(sh);
-          if (tid == 0) {
-            sh.retried++;
-            if (win_b - win_a <= 1) {
-              if (!sh.ev_failed) sh.failed++;  // events with a time bucket that alone exceeds the table
-              sh.ev_failed = 1;
+          if (tid < 64) {  // wave 0: same window start, smaller budget (a lone bucket is skipped)
+            const bool lone = win_b - win_a <= 1;  // one time bucket alone exceeds the table: not representable
+            const int budget = lone ? local_const(TARGET_KEYS) : (sh.win_samples / 2 > 0 ? sh.win_samples / 2 : 1);
+            if (tid == 0) {
+              sh.retried++;
+              if (lone) {
+                if (!sh.ev_failed) sh.failed++;  // events with a time bucket that alone exceeds the table
+                sh.ev_failed = 1;
+              }
               sh.overflow = 0;
-              sh.win_b = win_a + 1;   // skip this bucket
-              sh.budget = TARGET_KEYS;
-            } else {
-              sh.budget = sh.win_samples / 2 > 0 ? sh.win_samples / 2 : 1;
+              sh.n_keys = 0u;
             }
-            const int from = sh.overflow ? sh.win_a : sh.win_b;  // overflow: same start, smaller budget
-            sh.overflow = 0;
-            sh.n_keys = 0u;
-            select_window(sh, from);
+            select_window(sh, lone ? win_a + 1 : win_a, budget, lane);
           }
           __syncthreads();
           continue;
@@ -793,12 +813,13 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
           }
           sh.base = base;
           sh.n_keys = 0u;
+          PHASE_MARK(17);  // segment written
+        }
+        if (tid < 64) {  // wave 0 chooses the next window; the barrier after the row stores publishes it
           // adapt the estimate to this event: observed keys per estimated key of the last window
           const int ratio_x16 = sh.win_samples > 0 ? (int)(n_rows * 16u) / sh.win_samples : 16;
-          sh.budget = ratio_x16 > 0 ? TARGET_KEYS * 16 / ratio_x16 : TARGET_KEYS;
-          sh.budget = min(max(sh.budget, TARGET_KEYS / 8), TARGET_KEYS * 4);
-          PHASE_MARK(17);  // segment written
-          select_window(sh, win_b);  // the next window, published by the barrier after the row stores
+          const int budget = ratio_x16 > 0 ? TARGET_KEYS * 16 / ratio_x16 : TARGET_KEYS;
+          select_window(sh, win_b, min(max(budget, TARGET_KEYS / 8), TARGET_KEYS * 4), lane);
           PHASE_MARK(18);
         }
         __syncthreads();

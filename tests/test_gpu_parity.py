@@ -370,6 +370,11 @@ def test_invariance_chunks_shards_residency(ctx):
     parts = eng2.run(n, seed=8, first_event=0)["stats"]
     for k in ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_sample_limit"):
         assert whole[k] == parts[k], k
+    eng3 = _engine(inp, ctx, chunk_events=100)  # several track batches (8 scatter chunks each)
+    small = eng3.run(n, seed=8, first_event=0)["stats"]
+    for k in ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_sample_limit"):
+        assert whole[k] == small[k], k
+    assert small["launches_tracks"] == 4 and small["launches_scatter"] == 30
     a = eng2.run(n // 2, seed=8, first_event=0)["stats"]
     b = eng2.run(n - n // 2, seed=8, first_event=n // 2)["stats"]
     assert a["n_points"] + b["n_points"] == whole["n_points"]
@@ -403,6 +408,27 @@ def test_full_size_properties(ctx):
         key = res["points"][lo:hi, 0].astype(np.int64) * 1024 + np.floor(res["points"][lo:hi, 1]).astype(np.int64)
         assert len(np.unique(key)) == hi - lo
     assert (res["points"][:, 2] >= 0).all()
+
+
+def test_fetch_with_block_reserved_rows(ctx):
+    """A launch large enough for block-wise row reservations (holes between the workgroups' blocks):
+    the gathered CSR cloud reproduces the device-side checksums, so no row is lost or doubled."""
+    inp = Inputs("o16aa")
+    eng = _engine(inp, ctx)
+    n = 9000
+    res = eng.run(n, seed=12, first_event=77, fetch=True, capacity_per_event=9000)
+    st = res["stats"]
+    off, pts = res["offsets"], res["points"]
+    assert off[-1] == st["n_points"] == len(pts) and st["n_failed"] == 0
+    assert int(pts[:, 2].astype(np.uint64).sum(dtype=np.uint64)) == st["charge_checksum"]
+    event = np.repeat(np.arange(77, 77 + n, dtype=np.uint64), np.diff(off))
+    key = (np.floor(pts[:, 1]).astype(np.uint64) << np.uint64(14)) | pts[:, 0].astype(np.uint64)
+    assert int(((event << np.uint64(24)) + key).sum(dtype=np.uint64)) == st["key_checksum"]
+    for e in (0, 1234, n - 1):  # keys unique inside an event
+        k = key[off[e]:off[e + 1]]
+        assert len(np.unique(k)) == len(k)
+    resident = eng.run(n, seed=12, first_event=77)["stats"]
+    assert resident["key_checksum"] == st["key_checksum"] and resident["charge_checksum"] == st["charge_checksum"]
 
 
 def test_empty_and_errors(ctx):

@@ -604,6 +604,7 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
   if ((size_t)d->n_species * ATTPC_DEDX_NODES * sizeof(double) > 150 * 1024)
     return fail(ctx, ATTPC_E_INVALID, "stopping-power tables of %d species do not fit LDS (max 13)", d->n_species);
   if (!d->pad_lut || d->lut_n < 1) return fail(ctx, ATTPC_E_INVALID, "missing pad look-up table");
+  if (d->lut_n > 32000) return fail(ctx, ATTPC_E_INVALID, "pad look-up table larger than 32000 x 32000 (indices are staged as 16 bit)");
   if (d->windows_edge <= d->micromegas_edge) return fail(ctx, ATTPC_E_INVALID, "windows_edge <= micromegas_edge");
   if (!(d->length > 0.0) || !(d->w_value > 0.0)) return fail(ctx, ATTPC_E_INVALID, "length and w_value must be > 0");
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -623,12 +624,13 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
   int32_t rc;
   {  // device copy is TRANSPOSED ([iy][ix]): the scatter kernel's lanes are mesh rows (one ix each) that
      // step through iy together, so one gather instruction then reads neighbouring ix of the same
-     // iy row -- 1-2 cache lines per sample instead of one per lane
-    const size_t n = (size_t)d->lut_n;
-    std::vector<int16_t> lut_t(n * n);
+     // iy row -- 1-2 cache lines per sample instead of one per lane.  One extra row and column of -1
+     // (index lut_n) stand for "off the pad plane".
+    const size_t n = (size_t)d->lut_n, pitch = n + 1;
+    std::vector<int16_t> lut_t(pitch * pitch, (int16_t)-1);
     for (size_t ix = 0; ix < n; ++ix)
-      for (size_t iy = 0; iy < n; ++iy) lut_t[iy * n + ix] = d->pad_lut[ix * n + iy];
-    if ((rc = upload(ctx, ctx->det_allocs, lut_t.data(), n * n, &dv.pad_lut))) return rc;
+      for (size_t iy = 0; iy < n; ++iy) lut_t[iy * pitch + ix] = d->pad_lut[ix * n + iy];
+    if ((rc = upload(ctx, ctx->det_allocs, lut_t.data(), pitch * pitch, &dv.pad_lut))) return rc;
   }
   std::vector<double> tabs((size_t)d->n_species * ATTPC_DEDX_NODES);
   for (int s = 0; s < d->n_species; ++s) {

@@ -95,7 +95,8 @@ struct DetDev {
   double dv;              // drift velocity, m / time bucket (parameters.py:172-174)
   double mm_edge;
   int64_t mpgd_gain;
-  const int16_t* pad_lut; // folded whole-mm LUT, transposed: pad_lut[iy * lut_n + ix]
+  const int16_t* pad_lut; // folded whole-mm LUT, transposed and padded: pad_lut[iy * (lut_n + 1) + ix],
+                          // row / column lut_n = -1 (off the pad plane)
   int32_t lut_n, lut_lo;
   int32_t n_species, ode_substeps;
   const double* dedx;     // [n_species][ATTPC_DEDX_NODES]

@@ -124,9 +124,8 @@ struct __align__(16) ScatterShared {
   uint32_t keys[HASH_CAP];    // bits 0..13 pad, 14..23 time bucket, 24..26 position in `indices`
   uint2 queue[N_WAVES][WAVE_QUEUE + 2];  // per wave: (key|label, charge) of queued runs (+ dump slot);
                                          // the whole array is the slot list during a flush
-  double st_n[STAGE];
-  double st_wl[STAGE];        // longitudinal slice weight (1 without the extension)
-  short st_ix[STAGE][MESH];   // LUT row index of mesh line i, -1 = off the pad plane
+  double st_n[STAGE];         // electrons x gain (x the slice weight of the longitudinal extension)
+  short st_ix[STAGE][MESH];   // LUT index of mesh line i, lut_n = off the pad plane
   short st_iy[STAGE][MESH];
   int st_tb[STAGE];           // bits 0..9 time bucket, 24..26 position in `indices`, 30 point transport
   int blocks[ATTPC_MAX_SIM][MAX_BLOCKS_PER_TRACK];  // arena block ids of the event's tracks
@@ -476,7 +475,9 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
           const int wave = tid >> 6;
           uint2* __restrict__ queue = sh.queue[wave];
           const char* __restrict__ lut_bytes = reinterpret_cast<const char*>(lut);
-          const unsigned int row_pitch = 2u * (unsigned int)lut_n;  // bytes per iy row of the transposed LUT
+          // transposed LUT [iy][ix] with one extra row and column of -1: index lut_n stands for "off the
+          // pad plane", so off-plane pixels, missing rows and rows handled elsewhere need no masks
+          const unsigned int row_pitch = 2u * (unsigned int)(lut_n + 1);  // bytes per iy row
           unsigned int claimed = 0u;  // new keys of this wave (wave uniform)
           bool ok = true;
           for (int row0 = wave * 64; row0 < n_rows; row0 += SC_THREADS) {  // wave-uniform trip count
@@ -488,35 +489,39 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
             const bool point = (tbw & (1 << 30)) != 0;
             const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
             const double n_el = sh.st_n[st];
-            const double wl = sh.st_wl[st];  // 1 without the longitudinal extension
             const int ix = sh.st_ix[st][i];
             // the row's 10 iy indices (5 dwords) and weights (5 x 16 bytes)
             const uint32_t* __restrict__ iy32 = reinterpret_cast<const uint32_t*>(&sh.st_iy[st][0]);
             const double2* __restrict__ w2 = reinterpret_cast<const double2*>(&sh.wtab[i * MESH]);
-            int iy[MESH];
+            unsigned int iy[MESH];
             double w[MESH];
 #pragma unroll
             for (int j = 0; j < MESH; j += 2) {
               const uint32_t pair = iy32[j >> 1];
-              iy[j] = (int)(short)(pair & 0xffffu);
-              iy[j + 1] = (int)(short)(pair >> 16);
+              iy[j] = pair & 0xffffu;
+              iy[j + 1] = pair >> 16;
               const double2 ww = w2[j >> 1];
               w[j] = ww.x;
               w[j + 1] = ww.y;
             }
-            unsigned int valid = 0u;  // bit j: pixel j is on the LUT
+            // per-pixel electrons int(pdf h^2 n) (transporter.py:240-246) as u32; the centre pixel is the
+            // largest of the row, so one check bounds every run total of the row below 2^32
+            uint32_t el[MESH];
+#pragma unroll
+            for (int j = 0; j < MESH; ++j) el[j] = (uint32_t)(w[j] * n_el);  // cvt truncates
+            const bool big = el[MESH / 2] >= (1u << 28);
+            // point_transport (transporter.py:123-169, sigma == 0: all electrons straight down, row 0 /
+            // pixel 0 stand for the sample) and rows too large for u32 go pixel by pixel into the table
+            const bool slow = have && ix != lut_n && (point || big);
             int pad[MESH];
             {
-              // 10 independent gathers in flight (clamped addresses, 32-bit byte offsets from the uniform
-              // base).  The empty asm takes all ten results: without it the compiler sinks each load into
-              // a branch on its select condition and waits there -- ten serial L2 round trips.
-              const unsigned int col = 2u * (unsigned int)max(ix, 0);
+              // 10 independent gathers in flight (32-bit byte offsets from the uniform base).  The empty
+              // asm takes all ten results: without it the compiler sinks each load into a branch on its
+              // first use and waits there -- ten serial L2 round trips.
+              const unsigned int col = 2u * (unsigned int)((have && !slow) ? ix : lut_n);
 #pragma unroll
-              for (int j = 0; j < MESH; ++j) {
-                const unsigned int off = __umul24((unsigned int)max(iy[j], 0), row_pitch) + col;
-                pad[j] = (int)*reinterpret_cast<const int16_t*>(lut_bytes + off);
-                valid |= iy[j] >= 0 ? (1u << j) : 0u;
-              }
+              for (int j = 0; j < MESH; ++j)
+                pad[j] = (int)*reinterpret_cast<const int16_t*>(lut_bytes + (__umul24(iy[j], row_pitch) + col));
               asm volatile("" : "+v"(pad[0]), "+v"(pad[1]), "+v"(pad[2]), "+v"(pad[3]), "+v"(pad[4]), "+v"(pad[5]),
                            "+v"(pad[6]), "+v"(pad[7]), "+v"(pad[8]), "+v"(pad[9]));
             }
@@ -524,39 +529,24 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
             PHASE_SYNC;
             PHASE_MARK(8);
 #endif
-            // per-pixel electrons int(pdf h^2 n) (transporter.py:240-246) as u32; the centre pixel is the
-            // largest of the row, so one check bounds every run total of the row below 2^32
-            uint32_t el[MESH];
-#pragma unroll
-            for (int j = 0; j < MESH; ++j) el[j] = (uint32_t)((w[j] * wl) * n_el);  // cvt truncates
-            const bool big = el[MESH / 2] >= (1u << 28);
-            const bool on_plane = have && ix >= 0;
-            // point_transport (transporter.py:123-169, sigma == 0: all electrons straight down, row 0 /
-            // pixel 0 stand for the sample) and rows too large for u32 go pixel by pixel into the table
-            const bool slow = on_plane && (point || big);
             bool slow_ok = true;
             if (__any(slow)) {
               if (slow) {
 #pragma unroll 1
                 for (int j = 0; j < MESH && slow_ok; ++j) {
-                  if (!((valid >> j) & 1u) || (point && (i != 0 || j != 0))) continue;
-                  const unsigned int off = __umul24((unsigned int)iy[j], row_pitch) + 2u * (unsigned int)ix;
-                  const int p = (int)*reinterpret_cast<const int16_t*>(lut_bytes + off);
-                  const double q = ((point ? 1.0 : sh.wtab[i * MESH + j]) * wl) * n_el;
+                  if (point && (i != 0 || j != 0)) continue;
+                  const int p = (int)*reinterpret_cast<const int16_t*>(
+                      lut_bytes + (__umul24(iy[j], row_pitch) + 2u * (unsigned int)ix));
+                  const double q = (point ? 1.0 : sh.wtab[i * MESH + j]) * n_el;
                   if (p >= 0) slow_ok = table_add(sh, word_hi | (uint32_t)p, (unsigned long long)q);
                 }
               }
             }
-            const bool live = on_plane && !slow;
             // merge runs of equal pads: a run's total sits with its last pixel
             uint32_t run_q[MESH];
             uint32_t ends = 0u;  // bit j: pixel j ends a run on a real pad
             {
               uint32_t acc = 0u;
-#pragma unroll
-              for (int j = 0; j < MESH; ++j) {
-                pad[j] = (live && ((valid >> j) & 1u)) ? pad[j] : -1;
-              }
 #pragma unroll
               for (int j = 0; j < MESH; ++j) {
                 acc += pad[j] >= 0 ? el[j] : 0u;
@@ -626,11 +616,10 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
             const double x = (i == MESH - 1) ? xhi : (double)i * sx + xlo;
             const double y = (i == MESH - 1) ? yhi : (double)i * sy + ylo;
             const double fx = floor(x * 1000.0), fy = floor(y * 1000.0);
-            sh.st_ix[slot][i] = (fx >= lo_mm && fx < hi_mm) ? (short)((int)fx - lut_lo) : (short)-1;
-            sh.st_iy[slot][i] = (fy >= lo_mm && fy < hi_mm) ? (short)((int)fy - lut_lo) : (short)-1;
+            sh.st_ix[slot][i] = (fx >= lo_mm && fx < hi_mm) ? (short)((int)fx - lut_lo) : (short)lut_n;
+            sh.st_iy[slot][i] = (fy >= lo_mm && fy < hi_mm) ? (short)((int)fy - lut_lo) : (short)lut_n;
           }
-          sh.st_n[slot] = tn.y;
-          sh.st_wl[slot] = n_slices == 1 ? 1.0 : a.det.long_weights[sl];
+          sh.st_n[slot] = (n_slices == 1 ? 1.0 : a.det.long_weights[sl]) * tn.y;  // x 1.0 is exact
           sh.st_tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
         };
         if (sorted) {  // the window is perm[win_r0 .. win_r0 + win_n): stage it densely, STAGE entries per round

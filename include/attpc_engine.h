@@ -133,7 +133,7 @@ typedef struct attpc_det_desc {
      detector/index.md:130-133): > 0 spreads every sample over ATTPC_LONG_STEPS time slices,
      linspace(t - 3 sigma_l, t + 3 sigma_l), sigma_l = sqrt(2 D_l dv t / E) / dv time buckets,
      slice s carrying the fraction long_weights[s] (1-D Gaussian pdf x slice pitch) of each
-     pixel: electrons = int(pdf h^2 * long_weights[s] * n).  0 = reference behaviour. */
+     pixel: electrons = int(pdf h^2 * (long_weights[s] * n)).  0 = reference behaviour. */
   double longitudinal_diffusion; /* V */
   double long_weights[5];
 } attpc_det_desc;

@@ -531,7 +531,7 @@ static void transverse_transport(const orc_det_desc* det, double time, double cx
         int64_t tb = (int64_t)time;
         int64_t id = orc_pair(tb, pad);
         int64_t pixel =
-            (int64_t)(bivariate_normal_pdf(xs[i], ys[j], cx, cy, sigma_t) * (step_x * step_y) * wl * (double)electrons);
+            (int64_t)(bivariate_normal_pdf(xs[i], ys[j], cx, cy, sigma_t) * (step_x * step_y) * (wl * (double)electrons));
         dict_add(points, id, pixel, label);
       }
     }

@@ -245,6 +245,31 @@ def test_det_run_vs_oracle(ctx, orc, name, n):
     print(name, "cloud points", offsets[-1], "max |dq|", worst, stats)
 
 
+def test_small_diffusion_many_samples_per_window(ctx, orc):
+    """Tiny transverse diffusion: 1-3 keys per sample, so one window holds more entries than the
+    staging buffer (several staging rounds per window) and most mesh rows collapse into one run."""
+    from attpc_engine_amd.detector.simulator import simulate_batch
+    from attpc_engine_amd.detector.luts import build_det_desc
+    inp = Inputs("o16aa")
+    inp.config.det_params.diffusion = 0.004
+    nuclei = [nuclear_map.get_data(z, a) for z, a in inp.species]
+    det_raw, keep = build_det_desc(inp.config, nuclei, fold_beam=False)
+    seed, first, n = 41, 3, 16
+    vertex, p4, _, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
+    ctx._det_token = None
+    offsets, points, labels, stats = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, seed, inp.indices,
+                                                    first_event=first, ctx=ctx)
+    ctx._det_token = None
+    assert stats["n_failed"] == 0
+    for e in range(n):
+        ref_pts, ref_lab, _ = orc.simulate(det_raw, inp.layout, seed, first + e, p4[e], vertex[e], capacity=1 << 19)
+        a = sort_cloud(points[offsets[e]:offsets[e + 1]], labels[offsets[e]:offsets[e + 1]])
+        compare_clouds(*a, *sort_cloud(ref_pts, ref_lab))
+    samples_per_event = stats["n_track_samples"] / n
+    assert samples_per_event > 330 and offsets[-1] / stats["n_track_samples"] < 4  # > STAGE entries, few keys each
+    print("keys per sample", offsets[-1] / stats["n_track_samples"], "samples per event", samples_per_event)
+
+
 def test_zero_diffusion_and_skipped_rows(ctx, orc):
     """sigma_t == 0 -> point_transport path; a Z == 0 row in `indices` is skipped."""
     from attpc_engine_amd.detector.simulator import simulate_batch

@@ -191,10 +191,10 @@ int32_t run_scatter(attpc_ctx* ctx, const attpc_event_layout& lay, const TrackBu
   int32_t rc;
   if ((rc = ensure(ctx, ctx->out_ctrl, 32 * sizeof(unsigned long long)))) return rc;
   // launch geometry: persistent workgroups, one per compute unit, that take `batch` events per visit
-  // to the event counter and reserve output rows `row_block` at a time (small launches: batch 1 and
-  // exact reservations, so that short runs still spread over the chip and waste no rows)
+  // to the event counter and reserve output rows `row_block` at a time (small launches: exact
+  // reservations, so that short runs waste no rows)
   const uint32_t sc_wgs = std::min<uint32_t>((uint32_t)ctx->n_cus, n);
-  const uint32_t sc_batch = std::max<uint32_t>(1u, std::min<uint32_t>(8u, n / (sc_wgs * 8u)));
+  const uint32_t sc_batch = n / sc_wgs >= 64u ? 2u : 1u;  // the request for the next batch is hidden (scatter.hip)
   const int64_t est_rows = (int64_t)n * 9216;
   const uint32_t sc_row_block = est_rows / ((int64_t)sc_wgs * 16) >= 16384
                                     ? (uint32_t)std::min<int64_t>(est_rows / ((int64_t)sc_wgs * 16), 1 << 18) : 1u;

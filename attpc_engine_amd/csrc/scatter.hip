@@ -348,19 +348,26 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
   clear_table(sh);  // every flush leaves the table empty again
   unsigned long long my_charge = 0ull, my_keys = 0ull;
 
+  // Events come in batches of a.batch from a global counter.  The returning atomic on that hot address
+  // takes microseconds, so thread 0 asks for the NEXT batch while it works on the last event of the
+  // current one: right after its rows pass of the first window, where wave 0 (which has issue
+  // priority and finishes first) would otherwise just wait at the barrier for the other waves.
+  auto take_batch = [&]() -> uint32_t {
+    int zero = 0;
+    asm volatile("" : "+v"(zero));  // opaque address: keeps LLVM's atomic optimizer (readfirstlane) away
+    return (uint32_t)atomicAdd(&a.out.ctrl[CTRL_NEXT_EVENT + zero], (unsigned long long)a.batch);
+  };
+  uint32_t next_first = 0u;  // thread 0: first event of the next batch, once asked for
+  bool have_next = false;
+  if (tid == 0) sh.batch_first = take_batch();
   for (;;) {
     __syncthreads();  // the previous event is finished in every wave
-    if (tid == 0) {
-      int zero = 0;
-      asm volatile("" : "+v"(zero));
-      sh.batch_first = (uint32_t)atomicAdd(&a.out.ctrl[CTRL_NEXT_EVENT + zero], (unsigned long long)a.batch);
-    }
-    __syncthreads();
     const uint32_t batch_first = sh.batch_first;
     if (batch_first >= a.n_events) break;
     const uint32_t batch_end = min(batch_first + a.batch, a.n_events);
     for (uint32_t e_local = batch_first; e_local < batch_end; ++e_local) {
       if (e_local != batch_first) __syncthreads();
+      const bool last_of_batch = e_local + 1u == batch_end;
       const uint64_t event = a.first_event + e_local;
       const uint32_t track0 = (a.event0 + e_local) * (uint32_t)n_sim;
       // ---- per-event init ----
@@ -641,6 +648,10 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
             PHASE_COUNT(14, (n_stage * MESH + SC_THREADS - 1) / SC_THREADS);
             const bool ok = rows_round(n_stage);
             if (!ok) sh.overflow = 1;
+            if (last_of_batch && !have_next && tid == 0) {
+              next_first = take_batch();
+              have_next = true;
+            }
             __syncthreads();
             PHASE_MARK(4);
             if (sh.overflow) break;  // uniform: every thread sees the flag after the barrier
@@ -686,6 +697,10 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
             // rows -> runs -> this wave's queue -> table, 64 mesh rows per wave at a time
             const bool ok = rows_round(n_stage);
             if (!ok) sh.overflow = 1;
+            if (last_of_batch && !have_next && tid == 0) {
+              next_first = take_batch();
+              have_next = true;
+            }
             __syncthreads();
             PHASE_MARK(4);
             if (sh.overflow) {  // uniform: every thread sees the flag after the barrier
@@ -841,6 +856,10 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
         // staging overlap the store acknowledgements
         PHASE_MARK(7);
       }
+    }
+    if (tid == 0) {  // events without any window never reached the request above
+      sh.batch_first = have_next ? next_first : take_batch();
+      have_next = false;
     }
   }
   PHASE_FLUSH;

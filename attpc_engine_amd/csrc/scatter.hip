@@ -7,23 +7,27 @@
 // :78-120 (position_to_index: floor to whole mm), pairing.py (key), beam_pads.py (folded
 // into the LUT), simulator.py:19-49 (dict_to_points), :108-113 (tb jitter, 0 <= tb < 512).
 //
-// Execution model: one workgroup = one event; its dictionary is an open-addressing hash table
-// in LDS (u32 key|label word + f64 charge, 8192 slots = 96 KiB).  Per round:
-//   stage  (workgroup) one lane per kept track sample: sigma_t and the whole-mm LUT indices
-//          of the sample's 10 mesh columns / 10 mesh rows (20 floors instead of 200) -> LDS
+// Execution model: persistent workgroups of 1024 threads, one per compute unit, take events from a
+// global counter; one event at a time, its dictionary is an open-addressing hash table in LDS
+// (u32 key|label word + u64 charge, 8192 slots = 96 KiB, buckets of 4 keys).
+// Per event: the entries (samples x slices) are histogrammed by time bucket, prefix-summed and
+// sorted by time bucket once; events with more keys than the table should hold are cut into
+// time-bucket windows (a key contains its time bucket, so windows partition the key space) sized by
+// an estimated key count and cut back to a whole number of row passes.  Per window:
+//   stage  one lane per entry of the window: sigma_t and the whole-mm LUT indices of the entry's
+//          10 mesh columns / 10 mesh rows (20 floors instead of 200) -> LDS
 //   rows   (per wave, no workgroup barrier) one lane per mesh row: 10 pad look-ups in flight
-//          (2-byte gathers from the 625 KB LUT, L2 resident), truncate the 10 pixel charges,
-//          merge runs of equal pads in registers, write the runs (key|label, charge) to the
-//          wave's queue in LDS at positions from a wave prefix sum
-//   insert (same wave) one lane per queued run, all lanes busy: ds_read probe, ds_cmpst_b32
-//          to claim a slot, ds_max_u32 for the label, ds_add_f64 for the charge
+//          (2-byte gathers from the 625 KB LUT, L2 resident, transposed so that the rows of a sample
+//          read neighbouring addresses), the 10 pixel charges truncated to u32, runs of equal pads
+//          merged in registers, runs (key|label, charge) written to the wave's LDS queue at positions
+//          from a ballot prefix
+//   insert (same wave) one lane per queued run in one wave-uniform loop: ds_read_b128 bucket probe,
+//          ds_cmpst_b32 to claim a slot, ds_max_u32 for the label, ds_add_u64 for the charge
+//   flush  occupied slots compacted per wave, rows written (with the Philox time-bucket jitter) to a
+//          range of the output block this workgroup reserved, slots reset on the way
 // Merging before inserting cuts hash inserts ~7x (100 pixels -> ~15 pads per sample) and the
 // queue turns the sparse "which lanes end a run" pattern into dense wave work.  Pixel charges
-// are whole numbers far below 2^53, so f64 accumulation is exact and order independent.
-// Events with more keys than the table holds are cut into time-bucket windows (a key
-// contains its time bucket, so windows partition the key space; boundaries come from a
-// prefix sum of the per-bucket sample histogram); each window is flushed as one contiguous
-// block of rows (one global atomic per window reserves the range) and the table is reused.
+// are whole numbers far below 2^53, so integer accumulation is exact and order independent.
 // "label = last nucleus in `indices` order that touched the key" (transporter.py:249) is the
 // MAX position in `indices` over the touching nuclei, kept with ds_max_u32 on the key|label
 // word, so all nuclei of an event scatter concurrently.
@@ -31,7 +35,7 @@
 // pdf(pixel) h^2 depends only on the pixel index: (36/81)/(2 pi) exp(-(2/9)((i-4.5)^2+(j-4.5)^2))
 // because the mesh pitch is h = 6 sigma / 9; the 100 weights are a constant table.
 //
-// Bound: VALU/SALU issue + LDS atomics + LUT gathers; HBM traffic is the 32 B per output row
+// Bound: VALU issue (DESIGN.md 4.3 has the counters); HBM traffic is the 32 B per output row
 // (3 f64 + i64, the reference's own dtypes) and 32 B per track sample read.
 #include "tracks_args.hpp"
 
@@ -62,6 +66,7 @@ namespace attpc {
 #define PHASE_FLUSH
 #endif
 
+// Build-time tunables (the A/B variants of tools/ab_scatter.py are builds with other values)
 #ifndef ATTPC_SC_THREADS
 #define ATTPC_SC_THREADS 1024
 #endif
@@ -71,33 +76,33 @@ namespace attpc {
 #ifndef ATTPC_SC_STAGE
 #define ATTPC_SC_STAGE 320
 #endif
-constexpr int SC_THREADS = ATTPC_SC_THREADS;
-constexpr int STAGE = ATTPC_SC_STAGE;       // samples examined per round
-constexpr int HASH_BITS = ATTPC_SC_HASH_BITS;
-constexpr int HASH_CAP = 1 << HASH_BITS;    // slots
 #ifndef ATTPC_SC_WAVE_QUEUE
 #define ATTPC_SC_WAVE_QUEUE 256
 #endif
 #ifndef ATTPC_SC_WG_PER_CU
 #define ATTPC_SC_WG_PER_CU 1
 #endif
-constexpr int WAVE_QUEUE = ATTPC_SC_WAVE_QUEUE;  // queued runs per wave and pass (typ. ~190 per 64 mesh rows)
-constexpr int N_WAVES = SC_THREADS / 64;
-constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-constexpr int SEG_BLOCK = 16;            // segment slots reserved at a time
-constexpr int CTRL_NEXT_EVENT = 28;      // out.ctrl[]: next unassigned event of the launch
-constexpr int CTRL_ROWS = 30;            // out.ctrl[]: rows actually written ([0] is the reservation cursor)
-constexpr uint32_t KEY_MASK = 0x00FFFFFFu;
 #ifndef ATTPC_SC_TARGET_PCT
 #define ATTPC_SC_TARGET_PCT 50
 #endif
-constexpr int TARGET_KEYS = HASH_CAP * ATTPC_SC_TARGET_PCT / 100;          // aimed-at table fill: insert cost rises steeply beyond ~55 %
-// Estimated distinct keys a sample adds: its mesh is 6 sigma_t wide, pads have a ~4.9 mm pitch,
-// so it touches about (1 + 6 sigma_t / 4.9 mm)^2 pads; sigma_t^2 = 2 D dv tb / E.  `spread` =
-// (6 / 4.9 mm)^2 * 2 D dv / E is a per-configuration constant.  (Default detector: 3 keys at the
-// micromegas, 15 at tb 256, 28 at tb 511; the measured mean of the headline workload is 14.6.)
-// Windows are cut on the prefix sum of this estimate; the ratio observed/estimated of each
-// flushed window rescales the next one.
+constexpr int SC_THREADS = ATTPC_SC_THREADS;
+constexpr int N_WAVES = SC_THREADS / 64;
+constexpr int STAGE = ATTPC_SC_STAGE;            // entries staged per rows round
+constexpr int HASH_BITS = ATTPC_SC_HASH_BITS;
+constexpr int HASH_CAP = 1 << HASH_BITS;         // slots
+constexpr int TARGET_KEYS = HASH_CAP * ATTPC_SC_TARGET_PCT / 100;  // aimed-at fill: inserts slow down steeply beyond ~55 %
+constexpr int WAVE_QUEUE = ATTPC_SC_WAVE_QUEUE;  // queued runs per wave and pass (typ. ~190 per 64 mesh rows)
+constexpr int MESH = ATTPC_MESH_STEPS;
+constexpr int PIXELS = MESH * MESH;
+constexpr int BINS_PER_THREAD = (ATTPC_NUM_TB + SC_THREADS - 1) / SC_THREADS;
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t KEY_MASK = 0x00FFFFFFu;
+constexpr int SEG_BLOCK = 16;        // segment slots reserved at a time
+constexpr int CTRL_NEXT_EVENT = 28;  // out.ctrl[]: next unassigned event of the launch
+constexpr int CTRL_ROWS = 30;        // out.ctrl[]: rows actually written ([0] is the reservation cursor)
+static_assert(STAGE <= SC_THREADS, "one lane per staged entry");
+static_assert(2 * N_WAVES * (WAVE_QUEUE + 2) >= HASH_CAP, "the wave queues double as the slot list of a flush");
+
 // Drift time of slice `sl` of a sample created at time bucket t: the sample itself without the
 // longitudinal-diffusion extension, else numpy.linspace(t - 3 sigma_l, t + 3 sigma_l, 5)[sl] with
 // sigma_l = sqrt(2 D_l dv t / E) / dv time buckets.
@@ -108,15 +113,16 @@ __device__ __forceinline__ double slice_time(const DetDev& det, double t, int sl
   return sl == n_slices - 1 ? hi : (double)sl * ((hi - lo) / (double)(n_slices - 1)) + lo;
 }
 
+// Estimated distinct keys a sample adds: its mesh is 6 sigma_t wide, pads have a ~4.9 mm pitch,
+// so it touches about (1 + 6 sigma_t / 4.9 mm)^2 pads; sigma_t^2 = 2 D dv tb / E.  `spread` =
+// (6 / 4.9 mm)^2 * 2 D dv / E is a per-configuration constant.  (Default detector: 3 keys at the
+// micromegas, 15 at tb 256, 28 at tb 511; the measured mean of the headline workload is 14.6.)
+// Windows are cut on the prefix sum of this estimate; the ratio observed/estimated of each
+// flushed window rescales the next one.
 __device__ __forceinline__ int key_estimate(int tb, float spread) {
   const float r = 1.0f + sqrtf(spread * (float)tb);
   return (int)fminf(r * r + 0.5f, 100.0f);  // a sample has 100 pixels
 }
-constexpr int MESH = ATTPC_MESH_STEPS;
-constexpr int PIXELS = MESH * MESH;
-constexpr int BINS_PER_THREAD = (ATTPC_NUM_TB + SC_THREADS - 1) / SC_THREADS;
-static_assert(STAGE <= SC_THREADS, "one lane per staged sample");
-static_assert(2 * N_WAVES * (WAVE_QUEUE + 2) >= HASH_CAP, "the wave queues double as the slot list of a flush");
 
 struct __align__(16) ScatterShared {
   double wtab[PIXELS];        // first member: rows of 10 weights are read as five 16-byte pairs

@@ -7,12 +7,13 @@
 // runs classical RK4 on the reference's own output grid (DESIGN.md "Track integrator").
 //
 // Execution model: one lane = one nucleus.  Waves are persistent: a lane whose track has
-// ended pulls the next track id from a global counter (wave-aggregated atomic), so short
-// tracks (particle leaves the gas after ~100 samples) do not idle next to long ones (particle
-// ranges out, up to 10001 samples).  The stopping-power tables of all species live in LDS;
-// the per-lane state (6 phase-space doubles, event functions, cursors) lives in registers.
-// Kept samples (x, y, time bucket, electrons*gain) are appended to per-track chains of
-// 4 KiB arena blocks in HBM.
+// ended takes the next track id from its wave's batch (128 ids per returning atomic on the global
+// counter), so short tracks (particle leaves the gas after ~40 samples) do not idle next to long
+// ones (particle ranges out, up to 10001 samples).  The host launches the kernel per batch of
+// several scatter chunks so that every lane sees several tracks.  The stopping-power tables of all
+// species live in LDS; the per-lane state (6 phase-space doubles, event functions, cursors) lives
+// in registers.  Kept samples (x, y, time bucket, electrons*gain) are appended to per-track chains
+// of 4 KiB arena blocks in HBM; waves reserve arena blocks 64 at a time.
 //
 // Bound: f64 VALU (about 2 rsqrt + 45 fma-class ops per right-hand side, 4 per step) plus one
 // Philox + Box-Muller per two ionising samples; HBM traffic is 32 B per kept sample.

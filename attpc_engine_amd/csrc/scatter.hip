@@ -88,6 +88,8 @@ namespace attpc {
 constexpr int SC_THREADS = ATTPC_SC_THREADS;
 constexpr int N_WAVES = SC_THREADS / 64;
 constexpr int STAGE = ATTPC_SC_STAGE;            // entries staged per rows round
+constexpr int SORT_CAP = 1024;                   // events with at most this many entries are sorted by time bucket
+constexpr int SORT_PER_THREAD = (SORT_CAP + SC_THREADS - 1) / SC_THREADS;
 constexpr int HASH_BITS = ATTPC_SC_HASH_BITS;
 constexpr int HASH_CAP = 1 << HASH_BITS;         // slots
 constexpr int TARGET_KEYS = HASH_CAP * ATTPC_SC_TARGET_PCT / 100;  // aimed-at fill: inserts slow down steeply beyond ~55 %
@@ -140,7 +142,7 @@ struct __align__(16) ScatterShared {
   unsigned long long cum[ATTPC_NUM_TB];  // inclusive prefix sums per time bucket: low word estimated keys,
                                          // high word staged entries (samples x slices)
   unsigned long long wave_sum[SC_THREADS / 64];
-  unsigned short perm[SC_THREADS];  // entries (sample x slice) sorted by time bucket, events of <= SC_THREADS entries
+  unsigned short perm[SORT_CAP];    // entries (sample x slice) sorted by time bucket, events of <= SORT_CAP entries
   int stage_sum[2][SC_THREADS / 64];  // in-window entries per wave of a staging chunk (double buffered)
   int win_a, win_b, win_samples, win_r0, win_n, budget, overflow, done, ev_failed, failed, retried;
   unsigned int wg_cursor, n_keys, batch_first;
@@ -407,18 +409,24 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
       const int total_s = total * n_slices;  // entries = samples x slices
       // t < 0 (sigma_t would be NaN: undefined in the reference) and tb >= 512 (removed by the
       // 0 <= tb < 512 mask of simulator.py:111-113) never reach the output
-      const bool sorted = total_s <= SC_THREADS;  // one thread per entry: sort them by time bucket once
-      int my_tb = -1;
+      const bool sorted = total_s <= SORT_CAP;  // few enough entries: sort them by time bucket once
+      int my_tb[SORT_PER_THREAD];  // time bucket of this thread's entries tid, tid + SC_THREADS, ...
+#pragma unroll
+      for (int k = 0; k < SORT_PER_THREAD; ++k) my_tb[k] = -1;
       if (sorted) {
-        if (tid < total_s) {
-          const int c = tid / n_slices;
-          int isim;
-          const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
-          if (t >= 0.0) {
-            const double ts = slice_time(a.det, t, tid - c * n_slices, n_slices);
-            if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
-              my_tb = (int)ts;
-              atomicAdd(&sh.cum[my_tb], (1ull << 32) | (unsigned long long)key_estimate((int)fmin(t, 511.0), spread));
+#pragma unroll
+        for (int k = 0; k < SORT_PER_THREAD; ++k) {
+          const int cs = tid + k * SC_THREADS;
+          if (cs < total_s) {
+            const int c = cs / n_slices;
+            int isim;
+            const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
+            if (t >= 0.0) {
+              const double ts = slice_time(a.det, t, cs - c * n_slices, n_slices);
+              if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
+                my_tb[k] = (int)ts;
+                atomicAdd(&sh.cum[my_tb[k]], (1ull << 32) | (unsigned long long)key_estimate((int)fmin(t, 511.0), spread));
+              }
             }
           }
         }
@@ -461,9 +469,13 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
       }
       __syncthreads();
 
-      if (my_tb >= 0) {  // counting sort: a window is then a contiguous range of perm[]
-        const unsigned int before = my_tb > 0 ? (unsigned int)(sh.cum[my_tb - 1] >> 32) : 0u;
-        sh.perm[before + atomicAdd(&reinterpret_cast<uint32_t*>(&sh.st_ix[0][0])[my_tb], 1u)] = (unsigned short)tid;
+#pragma unroll
+      for (int k = 0; k < SORT_PER_THREAD; ++k) {
+        if (my_tb[k] >= 0) {  // counting sort: a window is then a contiguous range of perm[]
+          const unsigned int before = my_tb[k] > 0 ? (unsigned int)(sh.cum[my_tb[k] - 1] >> 32) : 0u;
+          sh.perm[before + atomicAdd(&reinterpret_cast<uint32_t*>(&sh.st_ix[0][0])[my_tb[k]], 1u)] =
+              (unsigned short)(tid + k * SC_THREADS);
+        }
       }
       if (tid < 64) select_window(sh, 0, local_const(TARGET_KEYS), lane);
       __syncthreads();

@@ -622,14 +622,14 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
   dv.longitudinal_diffusion = d->longitudinal_diffusion > 0.0 ? d->longitudinal_diffusion : 0.0;
   for (int s = 0; s < ATTPC_LONG_STEPS; ++s) dv.long_weights[s] = d->long_weights[s];
   int32_t rc;
-  {  // device copy is TRANSPOSED ([iy][ix]): the scatter kernel's lanes are mesh rows (one ix each) that
-     // step through iy together, so one gather instruction then reads neighbouring ix of the same
-     // iy row -- 1-2 cache lines per sample instead of one per lane.  One extra row and column of -1
-     // (index lut_n) stand for "off the pad plane".
+  {  // device copy: [x][y] as given, padded with one extra row and column of -1 (index lut_n = "off
+     // the pad plane").  The scatter kernel's lanes are mesh lines of constant y that step through x
+     // together, so one gather instruction reads neighbouring y of the same x row -- 1-2 cache lines
+     // per sample instead of one per lane.
     const size_t n = (size_t)d->lut_n, pitch = n + 1;
     std::vector<int16_t> lut_t(pitch * pitch, (int16_t)-1);
     for (size_t ix = 0; ix < n; ++ix)
-      for (size_t iy = 0; iy < n; ++iy) lut_t[iy * pitch + ix] = d->pad_lut[ix * n + iy];
+      for (size_t iy = 0; iy < n; ++iy) lut_t[ix * pitch + iy] = d->pad_lut[ix * n + iy];
     if ((rc = upload(ctx, ctx->det_allocs, lut_t.data(), pitch * pitch, &dv.pad_lut))) return rc;
   }
   std::vector<double> tabs((size_t)d->n_species * ATTPC_DEDX_NODES);

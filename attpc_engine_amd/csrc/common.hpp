@@ -95,7 +95,7 @@ struct DetDev {
   double dv;              // drift velocity, m / time bucket (parameters.py:172-174)
   double mm_edge;
   int64_t mpgd_gain;
-  const int16_t* pad_lut; // folded whole-mm LUT, transposed and padded: pad_lut[iy * (lut_n + 1) + ix],
+  const int16_t* pad_lut; // folded whole-mm LUT, padded: pad_lut[ix * (lut_n + 1) + iy],
                           // row / column lut_n = -1 (off the pad plane)
   int32_t lut_n, lut_lo;
   int32_t n_species, ode_substeps;

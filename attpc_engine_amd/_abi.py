@@ -114,7 +114,7 @@ class RunStats(C.Structure):
         ("charge_checksum", C.c_uint64), ("key_checksum", C.c_uint64),
         ("ms_kinematics", C.c_double), ("ms_tracks", C.c_double), ("ms_scatter", C.c_double),
         ("launches_kinematics", C.c_uint32), ("launches_tracks", C.c_uint32),
-        ("launches_scatter", C.c_uint32), ("reserved", C.c_uint32),
+        ("launches_scatter", C.c_uint32), ("n_inconsistent", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:

@@ -116,7 +116,7 @@ int32_t validate_layout(attpc_ctx* ctx, const attpc_event_layout* lay) {
 }
 
 struct ChunkResult {
-  unsigned long long rows = 0, segs = 0, charge = 0, keys = 0, failed = 0, retried = 0, samples = 0;
+  unsigned long long rows = 0, segs = 0, charge = 0, keys = 0, failed = 0, retried = 0, samples = 0, mismatch = 0;
   float ms_tracks = 0, ms_scatter = 0;
 };
 
@@ -193,7 +193,10 @@ int32_t run_scatter(attpc_ctx* ctx, const attpc_event_layout& lay, const TrackBu
   // launch geometry: persistent workgroups, one per compute unit, that take `batch` events per visit
   // to the event counter and reserve output rows `row_block` at a time (small launches: exact
   // reservations, so that short runs waste no rows)
-  const uint32_t sc_wgs = std::min<uint32_t>((uint32_t)ctx->n_cus, n);
+#ifndef ATTPC_SC_WG_PER_CU  // experiment builds with smaller workgroups (tools/ab_scatter.py) set this with the kernel macros
+#define ATTPC_SC_WG_PER_CU 1
+#endif
+  const uint32_t sc_wgs = std::min<uint32_t>((uint32_t)ctx->n_cus * ATTPC_SC_WG_PER_CU, n);
   const uint32_t sc_batch = n / sc_wgs >= 64u ? 2u : 1u;  // the request for the next batch is hidden (scatter.hip)
   const int64_t est_rows = (int64_t)n * 9216;
   const uint32_t sc_row_block = est_rows / ((int64_t)sc_wgs * 16) >= 16384
@@ -256,6 +259,7 @@ int32_t run_scatter(attpc_ctx* ctx, const attpc_event_layout& lay, const TrackBu
       res->failed = octrl[4];
       res->retried = octrl[5];
       res->samples = octrl[7];
+      res->mismatch = octrl[31];
       return ATTPC_OK;
     }
     // cloud / segment capacity exceeded (the cursors kept counting)
@@ -655,6 +659,7 @@ static void accumulate(attpc_run_stats* st, const ChunkResult& r) {
   st->key_checksum += r.keys;
   st->ms_scatter += r.ms_scatter;
   st->launches_scatter += 1;
+  st->n_inconsistent += (uint32_t)r.mismatch;
 }
 
 int32_t attpc_det_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,

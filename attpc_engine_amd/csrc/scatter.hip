@@ -102,6 +102,7 @@ constexpr uint32_t KEY_MASK = 0x00FFFFFFu;
 constexpr int SEG_BLOCK = 16;        // segment slots reserved at a time
 constexpr int CTRL_NEXT_EVENT = 28;  // out.ctrl[]: next unassigned event of the launch
 constexpr int CTRL_ROWS = 30;        // out.ctrl[]: rows actually written ([0] is the reservation cursor)
+constexpr int CTRL_MISMATCH = 31;    // out.ctrl[]: windows whose occupied-slot count differed from the claimed keys
 static_assert(STAGE <= SC_THREADS, "one lane per staged entry");
 static_assert(2 * N_WAVES * (WAVE_QUEUE + 2) >= HASH_CAP, "the wave queues double as the slot list of a flush");
 
@@ -327,7 +328,7 @@ __device__ __forceinline__ int fresh_tid() {
   return t;
 }
 
-__global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_kernel(ScatterArgs a) {
+__global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) void scatter_kernel(ScatterArgs a) {
   __shared__ ScatterShared sh;
   // tid / lane are re-read through an opaque asm at every use (macros below): otherwise the compiler
   // hoists every tid-derived LDS address of every phase to the top of the kernel, runs out of the 128
@@ -850,6 +851,7 @@ __global__ __launch_bounds__(SC_THREADS, 4 * ATTPC_SC_WG_PER_CU) void scatter_ke
         }
         __syncthreads();
         PHASE_MARK(6);
+        if (tid == 0 && sh.wg_cursor != n_rows) atomicAdd(&a.out.ctrl[CTRL_MISMATCH], 1ull);  // self-check, never seen
         const unsigned long long base = sh.base;
         for (unsigned int r = tid; r < n_rows; r += SC_THREADS) {
           const uint32_t slot = reinterpret_cast<const uint32_t*>(&sh.queue[0][0])[r];

@@ -159,8 +159,8 @@ typedef struct attpc_run_stats {
   uint64_t n_points;          /* cloud rows produced */
   uint64_t n_track_samples;   /* track samples with >= 1 electron (scatter work items) */
   uint64_t n_sample_limit;    /* events that hit event_sample_limit */
-  uint64_t n_lds_overflow;    /* events that took the HBM-hash fallback */
-  uint64_t n_failed;          /* events whose cloud could not be built (fallback overflow) */
+  uint64_t n_lds_overflow;    /* windows redone with a smaller time-bucket range (LDS table too full) */
+  uint64_t n_failed;          /* events with a single time bucket larger than the LDS table (bucket dropped) */
   uint64_t charge_checksum;   /* sum of all charges mod 2^64 */
   uint64_t key_checksum;      /* sum over points of (event*2^24 + tb*2^14 + pad) mod 2^64 */
   double ms_kinematics;       /* device time of each kernel family (HIP events on the ctx stream) */
@@ -169,7 +169,8 @@ typedef struct attpc_run_stats {
   uint32_t launches_kinematics;
   uint32_t launches_tracks;
   uint32_t launches_scatter;
-  uint32_t reserved;
+  uint32_t n_inconsistent;    /* self-check: flushed windows whose occupied-slot count differed from the
+                                 number of claimed keys; must be 0 */
 } attpc_run_stats;
 
 typedef struct attpc_ctx attpc_ctx;

@@ -30,8 +30,8 @@ def child(workloads_csv: str, n: int) -> None:
         ctx.lib.attpc_sync(ctx.handle)
         dt = time.perf_counter() - t0
         out[name] = {"ev_s": round(n / dt), "ms_tracks": round(st["ms_tracks"], 2), "ms_scatter": round(st["ms_scatter"], 2),
-                     "points": st["n_points"], "charge": st["charge_checksum"], "keys": st["key_checksum"],
-                     "failed": st["n_failed"], "retries": st["n_lds_overflow"]}
+                     "points": st["n_points"], "samples": st["n_track_samples"], "charge": st["charge_checksum"], "keys": st["key_checksum"],
+                     "failed": st["n_failed"], "retries": st["n_lds_overflow"], "inconsistent": st["n_inconsistent"]}
         if "phase_cycles" in st:
             out[name]["phase"] = st["phase_cycles"]
     print(json.dumps(out))

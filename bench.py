@@ -122,6 +122,7 @@ def main() -> None:
             "track_samples_per_event": stats["n_track_samples"] / max(1, n_events),
             "algorithmic_bytes_per_event": bytes_per_event,
             "failed_events": failed,
+            "table_self_check_failures": stats["n_inconsistent"],
             "sample_limit_events": limit,
             "charge_checksum": charge_sum,
             "key_checksum": key_sum,

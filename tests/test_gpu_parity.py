@@ -379,7 +379,7 @@ def test_bulk_checksums_vs_oracle(ctx, orc, name, n):
     assert st["key_checksum"] == ref[3] % (1 << 64)
     diff = (int(st["charge_checksum"]) - int(ref[2] % (1 << 64)) + (1 << 63)) % (1 << 64) - (1 << 63)
     assert abs(diff) <= 8 * st["n_points"], diff
-    assert st["n_failed"] == 0
+    assert st["n_failed"] == 0 and st["n_inconsistent"] == 0
     print(name, "points", st["n_points"], "charge checksum difference (electrons)", diff)
 
 
@@ -425,7 +425,7 @@ def test_full_size_properties(ctx):
     s2 = eng.run(n, seed=3)["stats"]
     for k in ("n_points", "charge_checksum", "key_checksum", "n_track_samples"):
         assert s1[k] == s2[k], k
-    assert s1["n_failed"] == 0 and s1["n_sample_limit"] == 0
+    assert s1["n_failed"] == 0 and s1["n_sample_limit"] == 0 and s1["n_inconsistent"] == 0
     assert 2000 < s1["n_points"] / n < 20000
     res = eng.run(64, seed=3, fetch=True)
     for e in range(64):

@@ -78,6 +78,8 @@ class DetDesc(C.Structure):
         ("species", SpeciesDesc * MAX_SPECIES),
         ("longitudinal_diffusion", C.c_double),
         ("long_weights", C.c_double * 5),
+        ("mc_diffusion", C.c_int32),
+        ("reserved_ext", C.c_int32),
     ]
 
 

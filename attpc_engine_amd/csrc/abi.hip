@@ -625,6 +625,9 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
   dv.n_species = d->n_species; dv.ode_substeps = d->ode_substeps > 0 ? d->ode_substeps : 1;
   dv.longitudinal_diffusion = d->longitudinal_diffusion > 0.0 ? d->longitudinal_diffusion : 0.0;
   for (int s = 0; s < ATTPC_LONG_STEPS; ++s) dv.long_weights[s] = d->long_weights[s];
+  dv.mc_diffusion = d->mc_diffusion != 0 ? 1 : 0;
+  dv.mpgd_gain32 = (int32_t)d->mpgd_gain;
+  if (dv.mc_diffusion && (d->mpgd_gain < 1 || d->mpgd_gain > 0x7fffffff)) return fail(ctx, ATTPC_E_INVALID, "mc_diffusion needs 1 <= mpgd_gain < 2^31");
   int32_t rc;
   {  // device copy: [x][y] as given, padded with one extra row and column of -1 (index lut_n = "off
      // the pad plane").  The scatter kernel's lanes are mesh lines of constant y that step through x

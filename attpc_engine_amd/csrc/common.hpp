@@ -21,6 +21,7 @@ constexpr double TWO_PI = 2.0 * PI;
 constexpr uint32_t DOMAIN_KIN = 0u;       // index = attempt * 64 + slot
 constexpr uint32_t DOMAIN_FANO0 = 1u;     // + row of the nucleus; index = sample >> 1
 constexpr uint32_t DOMAIN_JITTER = 0x100u; // index = tb << 14 | pad
+constexpr uint32_t DOMAIN_MC = 0x200u;     // + entry number of the event; index = primary electron
 constexpr uint32_t KIN_SLOTS = 64u;
 
 // Philox4x32-10 (Salmon et al. SC'11), the algorithm of rocRAND's default generator, written
@@ -104,6 +105,8 @@ struct DetDev {
   int32_t Z[ATTPC_MAX_SPECIES];
   double longitudinal_diffusion;            // extension, 0 = reference behaviour
   double long_weights[ATTPC_LONG_STEPS];
+  int32_t mc_diffusion;                     // extension: per-electron Monte-Carlo transverse diffusion
+  int32_t mpgd_gain32;
 };
 
 // track sample arena: blocks of ARENA_BLK samples, each sample = (x, y, time bucket, electrons)

@@ -127,6 +127,15 @@ __device__ __forceinline__ int key_estimate(int tb, float spread) {
   return (int)fminf(r * r + 0.5f, 100.0f);  // a sample has 100 pixels
 }
 
+// Monte-Carlo diffusion extension: what a staged entry needs instead of the mesh indices (these
+// records overlay st_ix / st_iy)
+struct McEntry {
+  double x, y, sigma;  // sample position [m], sigma_t [m]
+  uint32_t n_prim;     // primary electrons
+  uint32_t cs;         // entry number in the event (random-stream domain)
+};
+static_assert(sizeof(McEntry) * STAGE <= 2 * sizeof(short) * STAGE * MESH, "McEntry records overlay st_ix + st_iy");
+
 struct __align__(16) ScatterShared {
   double wtab[PIXELS];        // first member: rows of 10 weights are read as five 16-byte pairs
   unsigned long long chg[HASH_CAP];  // electrons per key (ds_add_u64)
@@ -328,6 +337,9 @@ __device__ __forceinline__ int fresh_tid() {
   return t;
 }
 
+// MC: the Monte-Carlo diffusion extension (its own instantiation, so that the default kernel keeps its
+// register budget)
+template <bool MC>
 __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) void scatter_kernel(ScatterArgs a) {
   __shared__ ScatterShared sh;
   // tid / lane are re-read through an opaque asm at every use (macros below): otherwise the compiler
@@ -496,7 +508,42 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
         int filled = 0;    // in-window entries of the chunks before this one
         bool stop = false;
         // One rows round over the staged entries.  Returns false when the table is too full.
+        // Monte-Carlo diffusion extension: a wave takes one staged entry at a time and moves its primary
+        // electrons 64 at a time: Philox pair (index = electron, domain = 0x200 + entry) -> Box-Muller ->
+        // position -> pad -> the same wave-level insert as the mesh path, int(w_slice * gain) electrons each.
+        auto rows_round_mc = [&](int n_stage) -> bool {
+          const int wave = tid >> 6;
+          const McEntry* __restrict__ entries = reinterpret_cast<const McEntry*>(&sh.st_ix[0][0]);
+          const double lo_mm = (double)lut_lo, hi_mm = (double)(lut_lo + lut_n);
+          unsigned int claimed = 0u;
+          bool ok = true;
+          for (int st = wave; st < n_stage && ok; st += N_WAVES) {  // wave uniform
+            const McEntry m = entries[st];
+            const int tbw = sh.st_tb[st];
+            const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
+            const uint32_t q = (uint32_t)sh.st_n[st];
+            for (uint32_t k0 = 0; k0 < m.n_prim && ok; k0 += 64u) {
+              const uint32_t k = k0 + (uint32_t)lane;
+              double ua, ub;
+              rng_pair(a.seed, event, k, DOMAIN_MC + m.cs, ua, ub);
+              const double rad = sqrt(-2.0 * log(1.0 - ua));
+              double sn, cs;
+              sincos(TWO_PI * ub, &sn, &cs);
+              // no FMA contraction: the oracle rounds the product before the sum
+              const double x = __dadd_rn(m.x, __dmul_rn(m.sigma, __dmul_rn(rad, cs)));
+              const double y = __dadd_rn(m.y, __dmul_rn(m.sigma, __dmul_rn(rad, sn)));
+              const double fx = floor(x * 1000.0), fy = floor(y * 1000.0);
+              const int ixx = (fx >= lo_mm && fx < hi_mm) ? (int)fx - lut_lo : lut_n;
+              const int iyy = (fy >= lo_mm && fy < hi_mm) ? (int)fy - lut_lo : lut_n;
+              const int pad = (int)lut[ixx * (lut_n + 1) + iyy];  // -1 off the plane / beam pad
+              ok = wave_insert(sh, word_hi | (uint32_t)max(pad, 0), q, k < m.n_prim && pad >= 0, claimed);
+            }
+          }
+          if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);
+          return ok;
+        };
         auto rows_round = [&](int n_stage) -> bool {
+          if constexpr (MC) return rows_round_mc(n_stage);
           const int n_rows = n_stage * MESH;
           const int wave = tid >> 6;
           uint2* __restrict__ queue = sh.queue[wave];
@@ -630,9 +677,19 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
         };
 
         // one (sample, slice) entry -> staging slot: sigma_t and the LUT indices of its 20 mesh lines
-        auto stage_entry = [&](int slot, double2 xy, double2 tn, int isim, int sl) {
+        auto stage_entry = [&](int slot, double2 xy, double2 tn, int isim, int sl, int cs) {
           const int tb = (int)slice_time(a.det, tn.x, sl, n_slices);  // transporter.py:238
           const double sigma = sqrt(2.0 * a.det.diffusion * a.det.dv * tn.x / a.det.efield);  // :301
+          if constexpr (MC) {  // extension: the electrons are moved one by one in rows_round_mc
+            McEntry m;
+            m.x = xy.x; m.y = xy.y; m.sigma = sigma;
+            m.n_prim = (uint32_t)(tn.y / (double)a.det.mpgd_gain32);  // tn.y = electrons x gain, an exact multiple
+            m.cs = (uint32_t)cs;
+            reinterpret_cast<McEntry*>(&sh.st_ix[0][0])[slot] = m;
+            sh.st_n[slot] = (double)(long long)((n_slices == 1 ? 1.0 : a.det.long_weights[sl]) * (double)a.det.mpgd_gain32);
+            sh.st_tb[slot] = tb | (isim << 24);
+            return;
+          }
           const double lo_mm = (double)lut_lo, hi_mm = (double)(lut_lo + lut_n);
           // numpy.linspace(c - 3 sigma, c + 3 sigma, 10) (:221-227) and position_to_index
           // (:107-118: whole-mm floor, low edge inclusive, high edge exclusive) per mesh line
@@ -662,7 +719,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
               int isim;
               const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
               stage_entry(tid, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1], isim,
-                          cs - c * n_slices);
+                          cs - c * n_slices, cs);
             }
             __syncthreads();
             PHASE_MARK(3);
@@ -706,7 +763,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
             filled_new += n_w;
           }
           const bool last_chunk = c0 + SC_THREADS >= total_s;
-          if (rank - round_lo >= 0 && rank - round_lo < STAGE) stage_entry(rank - round_lo, xy, tn, isim, sl);
+          if (rank - round_lo >= 0 && rank - round_lo < STAGE) stage_entry(rank - round_lo, xy, tn, isim, sl, c0 + tid);
           for (;;) {
             const int pending = filled_new - round_lo;  // staged entries, workgroup uniform
             if (pending < STAGE && !(last_chunk && pending > 0)) break;  // keep filling / nothing left
@@ -737,7 +794,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
               int isim2;
               const double* rec = sample_ptr(sh, arena, n_sim, c, isim2);
               stage_entry(rank - round_lo, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1],
-                          isim2, (c0 + tid) - c * n_slices);
+                          isim2, (c0 + tid) - c * n_slices, c0 + tid);
             }
           }
           filled = filled_new;
@@ -917,7 +974,10 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
 #undef lane
 
 void launch_scatter_kernel(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a) {
-  hipLaunchKernelGGL(scatter_kernel, dim3(n_workgroups), dim3(SC_THREADS), 0, s, a);
+  if (a.det.mc_diffusion)
+    hipLaunchKernelGGL(scatter_kernel<true>, dim3(n_workgroups), dim3(SC_THREADS), 0, s, a);
+  else
+    hipLaunchKernelGGL(scatter_kernel<false>, dim3(n_workgroups), dim3(SC_THREADS), 0, s, a);
 }
 
 }  // namespace attpc

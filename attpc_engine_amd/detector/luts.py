@@ -102,6 +102,7 @@ def build_det_desc(config, nuclei: list, ode_substeps: int = 1, fold_beam: bool 
     desc.longitudinal_diffusion = float(getattr(det, "longitudinal_diffusion", 0.0) or 0.0)
     for s, w in enumerate(longitudinal_weights()):
         desc.long_weights[s] = w
+    desc.mc_diffusion = 1 if getattr(det, "mc_diffusion", False) else 0
     for i, nuc in enumerate(nuclei):
         table = sample_dedx_table(det.gas_target, nuc)
         keep.append(table)

@@ -27,7 +27,9 @@ class DetectorParams:
     diffusion [V], fano_factor, w_value [eV] -- reference parameters.py:10-48.
 
     ``longitudinal_diffusion`` [V] is an opt-in EXTENSION (the reference has no longitudinal
-    diffusion, docs/user_guide/detector/index.md:130-133); 0 keeps the reference behaviour."""
+    diffusion, docs/user_guide/detector/index.md:130-133); 0 keeps the reference behaviour.
+    ``mc_diffusion`` (EXTENSION) replaces the deterministic 10x10 mesh by one Gaussian step per
+    primary electron (seeded, reproducible); False keeps the reference behaviour."""
 
     length: float
     efield: float
@@ -38,6 +40,7 @@ class DetectorParams:
     fano_factor: float
     w_value: float
     longitudinal_diffusion: float = 0.0
+    mc_diffusion: bool = False
 
 
 @dataclass

@@ -136,6 +136,13 @@ typedef struct attpc_det_desc {
      pixel: electrons = int(pdf h^2 * (long_weights[s] * n)).  0 = reference behaviour. */
   double longitudinal_diffusion; /* V */
   double long_weights[5];
+  /* EXTENSION (north star: "stochastic per-electron diffusion instead of the deterministic 10x10
+     mesh"): != 0 moves every primary electron k of an entry (sample x slice) by its own Gaussian
+     step, x = x0 + sigma_t N_x, y = y0 + sigma_t N_y (Box-Muller on the Philox pair with index k in
+     domain 0x200 + entry number), and adds int(w_slice * gain) electrons to the pad it lands on.
+     0 = the reference's mesh. */
+  int32_t mc_diffusion;
+  int32_t reserved_ext;
 } attpc_det_desc;
 
 /* which rows of an event are simulated, detector/simulator.py:96-101,157-158 */

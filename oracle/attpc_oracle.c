@@ -538,10 +538,34 @@ static void transverse_transport(const orc_det_desc* det, double time, double cx
   }
 }
 
-/* detector/transporter.py:252-317; track rows here are (x, y, time bucket) */
-void orc_transport_track(const orc_det_desc* det, const double* xyt, const int64_t* electrons, int32_t n,
-                         orc_dict* points, int64_t label) {
+/* EXTENSION (no reference counterpart): per-electron Monte-Carlo transverse diffusion.  Every
+ * primary electron k of entry `cs` lands at (cx + sigma N_x, cy + sigma N_y), Box-Muller on the
+ * Philox pair (index k, domain 0x200 + cs), and adds q electrons to the pad under it. */
+static void mc_transport(const orc_det_desc* det, double time, double cx, double cy, int64_t n_prim, int64_t q,
+                         double sigma_t, orc_dict* points, int64_t label, uint64_t seed, uint64_t event,
+                         uint32_t cs) {
+  int64_t tb = (int64_t)time;
+  for (int64_t k = 0; k < n_prim; ++k) {
+    double ua, ub;
+    orc_rng_pair(seed, event, (uint32_t)k, 0x200u + cs, &ua, &ub);
+    double rad = sqrt(-2.0 * log(1.0 - ua));
+    double x = cx + sigma_t * (rad * cos(2.0 * PI * ub));
+    double y = cy + sigma_t * (rad * sin(2.0 * PI * ub));
+    int64_t ix, iy;
+    if (!position_to_index(det, x, y, &ix, &iy)) continue;
+    int64_t pad = det->pad_lut[ix * det->lut_n + iy];
+    if (pad != -1 && !is_beam_pad(pad)) dict_add(points, orc_pair(tb, pad), q, label);
+  }
+}
+
+/* detector/transporter.py:252-317; track rows here are (x, y, time bucket).  seed / event /
+ * sample_base (kept samples of the event's earlier nuclei) only matter for the Monte-Carlo
+ * extension, whose random streams are keyed by the entry number (sample x slice) in the event. */
+static void transport_track_ex(const orc_det_desc* det, const double* xyt, const int64_t* electrons, int32_t n,
+                               orc_dict* points, int64_t label, uint64_t seed, uint64_t event,
+                               int64_t sample_base) {
   double dv = det->length / (double)(det->windows_edge - det->micromegas_edge);
+  const int n_slices = det->longitudinal_diffusion > 0.0 ? 5 : 1;
   for (int32_t i = 0; i < n; ++i) {
     double time = xyt[3 * i + 2];
     double sigma_t = sqrt(2.0 * det->diffusion * dv * time / det->efield);
@@ -553,20 +577,33 @@ void orc_transport_track(const orc_det_desc* det, const double* xyt, const int64
       for (int sl = 0; sl < 5; ++sl) {
         double ts = sl == 4 ? hi : (double)sl * step + lo;
         if (!(ts >= 0.0)) continue;
-        if (sigma_t == 0.0) point_transport(det, ts, xyt[3 * i], xyt[3 * i + 1], electrons[i], points, label, det->long_weights[sl]);
+        if (det->mc_diffusion)
+          mc_transport(det, ts, xyt[3 * i], xyt[3 * i + 1], electrons[i] / det->mpgd_gain,
+                       (int64_t)(det->long_weights[sl] * (double)det->mpgd_gain), sigma_t, points, label, seed, event,
+                       (uint32_t)((sample_base + i) * n_slices + sl));
+        else if (sigma_t == 0.0) point_transport(det, ts, xyt[3 * i], xyt[3 * i + 1], electrons[i], points, label, det->long_weights[sl]);
         else transverse_transport(det, ts, xyt[3 * i], xyt[3 * i + 1], electrons[i], sigma_t, points, label, det->long_weights[sl]);
       }
       continue;
     }
-    if (sigma_t == 0.0) point_transport(det, time, xyt[3 * i], xyt[3 * i + 1], electrons[i], points, label, 1.0);
+    if (det->mc_diffusion)
+      mc_transport(det, time, xyt[3 * i], xyt[3 * i + 1], electrons[i] / det->mpgd_gain, det->mpgd_gain, sigma_t, points,
+                   label, seed, event, (uint32_t)(sample_base + i));
+    else if (sigma_t == 0.0) point_transport(det, time, xyt[3 * i], xyt[3 * i + 1], electrons[i], points, label, 1.0);
     else transverse_transport(det, time, xyt[3 * i], xyt[3 * i + 1], electrons[i], sigma_t, points, label, 1.0);
   }
 }
 
+void orc_transport_track(const orc_det_desc* det, const double* xyt, const int64_t* electrons, int32_t n,
+                         orc_dict* points, int64_t label) {
+  transport_track_ex(det, xyt, electrons, n, points, label, 0, 0, 0);
+}
+
 /* detector/solver.py:350-413 */
-int32_t orc_generate_point_cloud(const orc_det_desc* det, const orc_species_desc* sp, const double mom[4],
-                                 const double vertex[3], uint64_t seed, uint64_t event, int64_t label,
-                                 orc_dict* points, double* samples_out, int32_t* n_track_rows) {
+static int32_t generate_point_cloud_ex(const orc_det_desc* det, const orc_species_desc* sp, const double mom[4],
+                                      const double vertex[3], uint64_t seed, uint64_t event, int64_t label,
+                                      orc_dict* points, double* samples_out, int32_t* n_track_rows,
+                                      int64_t sample_base) {
   double* track = (double*)malloc(sizeof(double) * 6 * ORC_TIME_SAMPLES);
   int64_t* electrons = (int64_t*)malloc(sizeof(int64_t) * ORC_TIME_SAMPLES);
   int32_t n = orc_generate_trajectory(det, sp, vertex, mom, track);
@@ -588,9 +625,15 @@ int32_t orc_generate_point_cloud(const orc_det_desc* det, const orc_species_desc
       m++;
     }
   }
-  orc_transport_track(det, xyt, electrons, m, points, label);
+  transport_track_ex(det, xyt, electrons, m, points, label, seed, event, sample_base);
   free(track); free(electrons); free(xyt);
   return m;
+}
+
+int32_t orc_generate_point_cloud(const orc_det_desc* det, const orc_species_desc* sp, const double mom[4],
+                                 const double vertex[3], uint64_t seed, uint64_t event, int64_t label,
+                                 orc_dict* points, double* samples_out, int32_t* n_track_rows) {
+  return generate_point_cloud_ex(det, sp, mom, vertex, seed, event, label, points, samples_out, n_track_rows, 0);
 }
 
 /* detector/simulator.py:52-115 (+ dict_to_points :19-49).  The tb jitter of a point is the
@@ -604,8 +647,8 @@ int64_t orc_simulate(const orc_det_desc* det, const orc_event_layout* lay, uint6
     int32_t row = lay->indices[i];
     int32_t sp = lay->species_of_row[row];
     if (sp < 0) continue; /* proton_numbers[idx] == 0, simulator.py:97-98 */
-    samples += (uint64_t)orc_generate_point_cloud(det, &det->species[sp], p4 + 4 * row, vertex, seed, event,
-                                                  (int64_t)row, d, NULL, NULL);
+    samples += (uint64_t)generate_point_cloud_ex(det, &det->species[sp], p4 + 4 * row, vertex, seed, event,
+                                                 (int64_t)row, d, NULL, NULL, (int64_t)samples);
   }
   if (n_track_samples) *n_track_samples = samples;
   int64_t n_out = 0;

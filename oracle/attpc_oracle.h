@@ -74,6 +74,8 @@ typedef struct {
   orc_species_desc species[ORC_MAX_SPECIES];
   double longitudinal_diffusion; /* extension, 0 = reference behaviour */
   double long_weights[5];
+  int32_t mc_diffusion;          /* extension: per-electron Monte-Carlo transverse diffusion */
+  int32_t reserved_ext;
 } orc_det_desc;
 
 typedef struct {

@@ -245,6 +245,32 @@ def test_det_run_vs_oracle(ctx, orc, name, n):
     print(name, "cloud points", offsets[-1], "max |dq|", worst, stats)
 
 
+@pytest.mark.parametrize("name,d_l", [("o16aa", 0.0), ("be10dp", 0.1)])
+def test_mc_diffusion_extension_vs_oracle(ctx, orc, name, d_l):
+    """Opt-in per-electron Monte-Carlo diffusion (extension), alone and on top of the longitudinal
+    slices: GPU vs oracle, exact keys / labels / charges (every electron carries int(w gain))."""
+    from attpc_engine_amd.detector.simulator import simulate_batch
+    from attpc_engine_amd.detector.luts import build_det_desc
+    inp = Inputs(name)
+    inp.config.det_params.mc_diffusion = True
+    inp.config.det_params.longitudinal_diffusion = d_l
+    nuclei = [nuclear_map.get_data(z, a) for z, a in inp.species]
+    det_raw, keep = build_det_desc(inp.config, nuclei, fold_beam=False)
+    seed, first, n = 23, 4, 10
+    vertex, p4, _, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
+    ctx._det_token = None
+    offsets, points, labels, stats = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, seed, inp.indices,
+                                                    first_event=first, ctx=ctx)
+    ctx._det_token = None
+    assert stats["n_failed"] == 0 and stats["n_inconsistent"] == 0
+    for e in range(n):
+        ref_pts, ref_lab, _ = orc.simulate(det_raw, inp.layout, seed, first + e, p4[e], vertex[e], capacity=1 << 20)
+        a = sort_cloud(points[offsets[e]:offsets[e + 1]], labels[offsets[e]:offsets[e + 1]])
+        compare_clouds(*a, *sort_cloud(ref_pts, ref_lab), charge_tol=0.0)
+    assert offsets[-1] > 1000
+    print(name, "MC points", offsets[-1], stats)
+
+
 def test_small_diffusion_many_samples_per_window(ctx, orc):
     """Tiny transverse diffusion: 1-3 keys per sample, so one window holds more entries than the
     staging buffer (several staging rounds per window) and most mesh rows collapse into one run."""

@@ -358,3 +358,30 @@ def test_longitudinal_extension_oracle():
         wsum = sum(wi for wi, t in zip(w, ts) if t >= 0.0)
         assert 0.9 * wsum * c0s.sum() < c1s.sum() <= wsum * c0s.sum() * 1.001
     assert len(keys) > len(base[0]) and set(labels.tolist()) == {2}
+
+
+def test_mc_diffusion_extension_oracle():
+    """Opt-in per-electron Monte-Carlo diffusion (no reference counterpart: 'parity unpinned', checked
+    against its definition): every primary electron puts `gain` electrons on exactly one pad, so the
+    cloud charge is gain x (primary electrons that land on the pad plane, off the beam pads); the
+    charge-weighted spread of a sample matches sigma_t; the run is reproducible and seed dependent."""
+    from attpc_engine_amd.detector.luts import build_det_desc
+    inp = Inputs("o16aa")
+    nuclei = [nuclear_map.get_data(z, a) for z, a in inp.species]
+    inp.config.det_params.mc_diffusion = True
+    det_mc, keep = build_det_desc(inp.config, nuclei, fold_beam=False)
+    assert det_mc.mc_diffusion == 1
+    gain = int(inp.config.det_params.mpgd_gain)
+    vertex, p4, _, _ = orc.kin_batch(inp.kin, 7, 0, 3, threads=2)
+    for e in range(3):
+        pts, lab, samples = orc.simulate(det_mc, inp.layout, 7, e, p4[e], vertex[e], capacity=1 << 19)
+        again, _, _ = orc.simulate(det_mc, inp.layout, 7, e, p4[e], vertex[e], capacity=1 << 19)
+        other, _, _ = orc.simulate(det_mc, inp.layout, 8, e, p4[e], vertex[e], capacity=1 << 19)
+        np.testing.assert_array_equal(pts, again)
+        assert len(other) != len(pts) or not np.array_equal(other, pts)
+        ref, _, _ = orc.simulate(inp.det_raw, inp.layout, 7, e, p4[e], vertex[e], capacity=1 << 19)
+        assert np.all(pts[:, 2] % gain == 0) and pts[:, 2].min() >= gain
+        # same primaries as the mesh run, whose 100 weights sum to 1.03 (nodes on the +-3 sigma edges count
+        # as whole cells) and which truncates per pixel
+        assert 0.95 < ref[:, 2].sum() / pts[:, 2].sum() < 1.06
+        assert abs(np.average(pts[:, 1], weights=pts[:, 2]) - np.average(ref[:, 1], weights=ref[:, 2])) < 2.0

@@ -24,11 +24,18 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
   return x;
 }
 
+constexpr int NREG = 88;  // per-thread register state that must survive: fills the 128-VGPR budget
+
 __global__ __launch_bounds__(THREADS, 4) void stress(unsigned long long* errors, int reps, int inserts) {
   __shared__ Shared sh;
   unsigned int ref_occ = 0;
   unsigned long long ref_sum = 0;
+  uint32_t r[NREG];
+#pragma unroll
+  for (int i = 0; i < NREG; ++i) r[i] = threadIdx.x * 977u + blockIdx.x * 131u + (uint32_t)i;
   for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) r[i] = r[i] * 1664525u + 1013904223u + (uint32_t)i;
     for (int i = threadIdx.x; i < SLOTS; i += THREADS) { sh.keys[i] = EMPTY; sh.chg[i] = 0ull; }
     if (threadIdx.x == 0) { sh.occupied = 0; sh.n_claimed = 0; sh.sum = 0; }
     __syncthreads();
@@ -73,6 +80,18 @@ __global__ __launch_bounds__(THREADS, 4) void stress(unsigned long long* errors,
     }
     __syncthreads();
   }
+  // the register state must equal its recomputation
+  unsigned int bad = 0;
+#pragma unroll 1
+  for (int i = 0; i < NREG; ++i) {
+    uint32_t e = threadIdx.x * 977u + blockIdx.x * 131u + (uint32_t)i;
+    for (int rep = 0; rep < reps; ++rep) e = e * 1664525u + 1013904223u + (uint32_t)i;
+    uint32_t got = 0;
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) got = k == i ? r[k] : got;
+    bad += got != e;
+  }
+  if (bad) atomicAdd(errors + 1, (unsigned long long)bad);
 }
 
 int main(int argc, char** argv) {
@@ -80,18 +99,19 @@ int main(int argc, char** argv) {
   int cus = 0;
   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
   unsigned long long* d_err;
-  hipMalloc(&d_err, sizeof(unsigned long long));
-  hipMemset(d_err, 0, sizeof(unsigned long long));
+  hipMalloc(&d_err, 2 * sizeof(unsigned long long));
+  hipMemset(d_err, 0, 2 * sizeof(unsigned long long));
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  stress<<<cus * per_cu, THREADS>>>(d_err, 400, 10);
+  stress<<<cus * per_cu, THREADS>>>(d_err, 4000, 10);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  unsigned long long err = 0;
-  hipMemcpy(&err, d_err, sizeof err, hipMemcpyDeviceToHost);
-  printf("%d workgroups per CU (%d workgroups, %zu B LDS each): %.1f ms, %llu repetitions disagreed with their first\n",
-         per_cu, cus * per_cu, sizeof(Shared), ms, err);
+  unsigned long long err2[2] = {0, 0};
+  hipMemcpy(err2, d_err, sizeof err2, hipMemcpyDeviceToHost);
+  const unsigned long long err = err2[0];
+  printf("%d workgroups per CU (%d workgroups, %zu B LDS each): %.1f ms, %llu repetitions disagreed with their first, %llu corrupted registers\n",
+         per_cu, cus * per_cu, sizeof(Shared), ms, err, err2[1]);
   return 0;
 }

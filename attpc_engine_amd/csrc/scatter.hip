@@ -331,6 +331,17 @@ __device__ __forceinline__ int local_const(int value) {
   return value;
 }
 
+// Workgroup barrier with an explicit wait for this wave's own LDS operations.  hipcc places
+// `s_waitcnt lgkmcnt(0)` in front of most `s_barrier`s by itself, but not in front of the one at the
+// head of the batch loop: thread 0's `ds_write` of the next batch index (issued on the loop's back
+// edge) could still be queued when the barrier released the other waves, which then read the OLD index
+// and worked on another event than wave 0.  Never seen with one workgroup per CU; about once per
+// 20 000 windows when two workgroups share a CU and contend for the LDS (found with that build).
+__device__ __forceinline__ void block_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 __device__ __forceinline__ int fresh_tid() {
   int t = (int)threadIdx.x;
   asm volatile("" : "+v"(t));
@@ -382,12 +393,12 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
   bool have_next = false;
   if (tid == 0) sh.batch_first = take_batch();
   for (;;) {
-    __syncthreads();  // the previous event is finished in every wave
+    block_sync();  // the previous event is finished in every wave
     const uint32_t batch_first = sh.batch_first;
     if (batch_first >= a.n_events) break;
     const uint32_t batch_end = min(batch_first + a.batch, a.n_events);
     for (uint32_t e_local = batch_first; e_local < batch_end; ++e_local) {
-      if (e_local != batch_first) __syncthreads();
+      if (e_local != batch_first) block_sync();
       const bool last_of_batch = e_local + 1u == batch_end;
       const uint64_t event = a.first_event + e_local;
       const uint32_t track0 = (a.event0 + e_local) * (uint32_t)n_sim;
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
         const int k = i / MAX_BLOCKS_PER_TRACK, b = i - k * MAX_BLOCKS_PER_TRACK;
         sh.blocks[k][b] = a.trk.block_table[(size_t)(track0 + k) * MAX_BLOCKS_PER_TRACK + b];
       }
-      __syncthreads();
+      block_sync();
       const int total = sh.cnt[ATTPC_MAX_SIM];
       PHASE_MARK(0);
 
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
           }
         }
       }
-      __syncthreads();
+      block_sync();
       {  // inclusive prefix sum over the 512 buckets: per-thread serial part, wave scan, wave offsets
         unsigned long long local[BINS_PER_THREAD];
         unsigned long long v = 0ull;
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
           incl += lane >= off ? up : 0ull;
         }
         if (lane == 63) sh.wave_sum[tid >> 6] = incl;
-        __syncthreads();
+        block_sync();
         unsigned long long offset = incl - v;
         for (int w = 0; w < (tid >> 6); ++w) offset += sh.wave_sum[w];
 #pragma unroll
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
           if (bin < ATTPC_NUM_TB) sh.cum[bin] = local[k] + offset;
         }
       }
-      __syncthreads();
+      block_sync();
 
 #pragma unroll
       for (int k = 0; k < SORT_PER_THREAD; ++k) {
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
         }
       }
       if (tid < 64) select_window(sh, 0, local_const(TARGET_KEYS), lane);
-      __syncthreads();
+      block_sync();
       PHASE_MARK(1);
 
       for (;;) {
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
               stage_entry(tid, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1], isim,
                           cs - c * n_slices, cs);
             }
-            __syncthreads();
+            block_sync();
             PHASE_MARK(3);
             PHASE_COUNT(12, 1);
             PHASE_COUNT(13, n_stage);
@@ -732,7 +743,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
               next_first = take_batch();
               have_next = true;
             }
-            __syncthreads();
+            block_sync();
             PHASE_MARK(4);
             if (sh.overflow) break;  // uniform: every thread sees the flag after the barrier
           }
@@ -752,7 +763,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
           }
           const unsigned long long bal = __ballot(in_win);
           if (lane == 0) sh.stage_sum[chunk & 1][tid >> 6] = __popcll(bal);
-          __syncthreads();
+          block_sync();
           // rank among the window's entries; entries outside the window never match a staging slot
           int rank = in_win ? filled + (int)__popcll(bal & ((1ull << lane) - 1ull)) : -(1 << 30);
           int filled_new = filled;
@@ -768,7 +779,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
             const int pending = filled_new - round_lo;  // staged entries, workgroup uniform
             if (pending < STAGE && !(last_chunk && pending > 0)) break;  // keep filling / nothing left
             const int n_stage = min(pending, STAGE);
-            __syncthreads();
+            block_sync();
             PHASE_MARK(3);
             PHASE_COUNT(12, 1);                                          // rows rounds
             PHASE_COUNT(13, n_stage);                                    // staged entries
@@ -781,7 +792,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
               next_first = take_batch();
               have_next = true;
             }
-            __syncthreads();
+            block_sync();
             PHASE_MARK(4);
             if (sh.overflow) {  // uniform: every thread sees the flag after the barrier
               stop = true;
@@ -801,7 +812,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
         }
 
         if (sh.overflow) {
-          __syncthreads();
+          block_sync();
           clear_table(sh);
           if (tid < 64) {  // wave 0: same window start, smaller budget (a lone bucket is skipped)
             const bool lone = win_b - win_a <= 1;  // one time bucket alone exceeds the table: not representable
@@ -817,7 +828,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
             }
             select_window(sh, lone ? win_a + 1 : win_a, budget, lane);
           }
-          __syncthreads();
+          block_sync();
           continue;
         }
 
@@ -849,7 +860,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
             sh.wg_rows += n_rows;
           }
         }
-        __syncthreads();
+        block_sync();
         PHASE_MARK(19);
         {  // every wave compacts its own contiguous slice of the table with a single LDS atomic
           constexpr int PER_WAVE = HASH_CAP / N_WAVES;
@@ -906,7 +917,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
           select_window(sh, win_b, min(max(budget, TARGET_KEYS / 8), TARGET_KEYS * 4), lane);
           PHASE_MARK(18);
         }
-        __syncthreads();
+        block_sync();
         PHASE_MARK(6);
         if (tid == 0 && sh.wg_cursor != n_rows) atomicAdd(&a.out.ctrl[CTRL_MISMATCH], 1ull);  // self-check, never seen
         const unsigned long long base = sh.base;
@@ -954,7 +965,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
     if (my_charge) atomicAdd(&sh.charge_sum, my_charge);
     if (my_keys) atomicAdd(&sh.key_sum, my_keys);
   }
-  __syncthreads();
+  block_sync();
   if (tid == 0) {
     if (sh.wg_samples) atomicAdd(&a.out.ctrl[7], sh.wg_samples);
     if (sh.wg_rows) atomicAdd(&a.out.ctrl[CTRL_ROWS], sh.wg_rows);

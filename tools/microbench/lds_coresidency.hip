@@ -26,7 +26,8 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
 
 constexpr int NREG = 88;  // per-thread register state that must survive: fills the 128-VGPR budget
 
-__global__ __launch_bounds__(THREADS, 4) void stress(unsigned long long* errors, int reps, int inserts) {
+__global__ __launch_bounds__(THREADS, 4) void stress(unsigned long long* errors, int reps, int inserts,
+                                                    const int16_t* __restrict__ table, uint32_t table_n) {
   __shared__ Shared sh;
   unsigned int ref_occ = 0;
   unsigned long long ref_sum = 0;
@@ -39,6 +40,21 @@ __global__ __launch_bounds__(THREADS, 4) void stress(unsigned long long* errors,
     for (int i = threadIdx.x; i < SLOTS; i += THREADS) { sh.keys[i] = EMPTY; sh.chg[i] = 0ull; }
     if (threadIdx.x == 0) { sh.occupied = 0; sh.n_claimed = 0; sh.sum = 0; }
     __syncthreads();
+    {  // ten scattered 2-byte gathers in flight from a table that does not fit the L1, like the pad LUT
+      int got[10];
+      uint32_t idx[10];
+#pragma unroll
+      for (int g = 0; g < 10; ++g) {
+        idx[g] = mix(blockIdx.x * 2654435761u + threadIdx.x * 40503u + (uint32_t)(rep * 10 + g)) % table_n;
+        got[g] = (int)*reinterpret_cast<const int16_t*>(reinterpret_cast<const char*>(table) + 2u * idx[g]);
+      }
+      asm volatile("" : "+v"(got[0]), "+v"(got[1]), "+v"(got[2]), "+v"(got[3]), "+v"(got[4]), "+v"(got[5]), "+v"(got[6]),
+                   "+v"(got[7]), "+v"(got[8]), "+v"(got[9]));
+      unsigned int wrong = 0;
+#pragma unroll
+      for (int g = 0; g < 10; ++g) wrong += got[g] != (int)(int16_t)(mix(idx[g]) & 0x7fffu);
+      if (wrong) atomicAdd(errors + 2, (unsigned long long)wrong);
+    }
     for (int k = 0; k < inserts; ++k) {
       // ~1500 distinct 24-bit keys per workgroup, each inserted ~3.4 times
       const uint32_t key = mix(blockIdx.x * 7919u + (uint32_t)((threadIdx.x * inserts + k) % 1500)) & 0xFFFFFFu;
@@ -99,19 +115,29 @@ int main(int argc, char** argv) {
   int cus = 0;
   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
   unsigned long long* d_err;
-  hipMalloc(&d_err, 2 * sizeof(unsigned long long));
-  hipMemset(d_err, 0, 2 * sizeof(unsigned long long));
+  hipMalloc(&d_err, 3 * sizeof(unsigned long long));
+  hipMemset(d_err, 0, 3 * sizeof(unsigned long long));
+  const uint32_t table_n = 313600;  // 560 x 560 int16, the size of the pad LUT
+  int16_t* h_table = (int16_t*)malloc(table_n * sizeof(int16_t));
+  for (uint32_t i = 0; i < table_n; ++i) {
+    uint32_t x = i;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    h_table[i] = (int16_t)(x & 0x7fffu);
+  }
+  int16_t* d_table;
+  hipMalloc(&d_table, table_n * sizeof(int16_t));
+  hipMemcpy(d_table, h_table, table_n * sizeof(int16_t), hipMemcpyHostToDevice);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  stress<<<cus * per_cu, THREADS>>>(d_err, 4000, 10);
+  stress<<<cus * per_cu, THREADS>>>(d_err, 4000, 10, d_table, table_n);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  unsigned long long err2[2] = {0, 0};
+  unsigned long long err2[3] = {0, 0, 0};
   hipMemcpy(err2, d_err, sizeof err2, hipMemcpyDeviceToHost);
   const unsigned long long err = err2[0];
-  printf("%d workgroups per CU (%d workgroups, %zu B LDS each): %.1f ms, %llu repetitions disagreed with their first, %llu corrupted registers\n",
-         per_cu, cus * per_cu, sizeof(Shared), ms, err, err2[1]);
+  printf("%d workgroups per CU (%d workgroups, %zu B LDS each): %.1f ms, %llu repetitions disagreed with their first, %llu corrupted registers, %llu wrong gathers\n",
+         per_cu, cus * per_cu, sizeof(Shared), ms, err, err2[1], err2[2]);
   return 0;
 }

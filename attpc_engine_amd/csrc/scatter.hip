@@ -39,7 +39,18 @@
 // (3 f64 + i64, the reference's own dtypes) and 32 B per track sample read.
 #include "tracks_args.hpp"
 
+// This file is compiled twice into the library: as it is ("big": one 1024-thread workgroup with an
+// 8192-slot table per CU) and through scatter_small.hip ("small": two 512-thread workgroups with
+// 4096-slot tables per CU, 6 % faster for detectors with the usual diffusion, but a single time bucket
+// with more than 4096 keys does not fit).  The host picks the variant per launch (abi.hip).
+#ifndef ATTPC_SC_VARIANT
+#define ATTPC_SC_VARIANT big
+#endif
+#define ATTPC_SC_CAT2(a, b) a##b
+#define ATTPC_SC_CAT(a, b) ATTPC_SC_CAT2(a, b)
+
 namespace attpc {
+namespace ATTPC_SC_CAT(sc_, ATTPC_SC_VARIANT) {
 
 // Diagnostic build only (-DATTPC_PHASE_TIMERS): thread 0 of every workgroup accumulates
 // s_memtime deltas per phase into out.ctrl[8 + phase]; never compiled into the shipped library.
@@ -357,8 +368,8 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
   // hoists every tid-derived LDS address of every phase to the top of the kernel, runs out of the 128
   // VGPRs a 1024-thread workgroup allows and reloads them from scratch memory (a global round trip
   // each) inside the per-window code
-#define tid (attpc::fresh_tid())
-#define lane (attpc::fresh_tid() & 63)
+#define tid (fresh_tid())
+#define lane (fresh_tid() & 63)
   const int n_sim = a.layout.n_sim;
   const int lut_n = a.det.lut_n, lut_lo = a.det.lut_lo;
   const int16_t* __restrict__ lut = a.det.pad_lut;
@@ -984,7 +995,10 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
 #undef tid
 #undef lane
 
-void launch_scatter_kernel(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a) {
+}  // namespace sc_<variant>
+
+void ATTPC_SC_CAT(launch_scatter_kernel_, ATTPC_SC_VARIANT)(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a) {
+  using namespace ATTPC_SC_CAT(sc_, ATTPC_SC_VARIANT);
   if (a.det.mc_diffusion)
     hipLaunchKernelGGL(scatter_kernel<true>, dim3(n_workgroups), dim3(SC_THREADS), 0, s, a);
   else

@@ -1,0 +1,8 @@
+// scatter_small.hip -- the scatter kernel with two 512-thread workgroups per CU (4096-slot tables).
+// Same source as scatter.hip, other build-time constants; see the note at the top of scatter.hip.
+#define ATTPC_SC_VARIANT small
+#define ATTPC_SC_THREADS 512
+#define ATTPC_SC_HASH_BITS 12
+#define ATTPC_SC_STAGE 112
+#define ATTPC_SC_WG_PER_CU 2
+#include "scatter.hip"

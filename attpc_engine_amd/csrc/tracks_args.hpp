@@ -37,7 +37,9 @@ void launch_kin_calculate(hipStream_t s, const attpc_kin_desc& d, uint32_t n, co
 void launch_decay_calculate(hipStream_t s, uint32_t n, const double* parent, double m1, double m2, const double* ex,
                             const double* th, const double* ph, double* out, int32_t* status);
 void launch_track_kernel(uint32_t blocks, size_t lds_bytes, hipStream_t s, const TrackArgs& a);
-void launch_scatter_kernel(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a);
+// scatter.hip compiled as it is / through scatter_small.hip (workgroups per CU: 1 / 2)
+void launch_scatter_kernel_big(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a);
+void launch_scatter_kernel_small(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a);
 
 // response + threshold + Spyral rows on device (spyral.hip)
 struct SpyralDev {

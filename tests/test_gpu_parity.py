@@ -462,6 +462,28 @@ def test_full_size_properties(ctx):
     assert (res["points"][:, 2] >= 0).all()
 
 
+def test_kernel_variants_agree_and_small_falls_back(monkeypatch):
+    """The scatter kernel exists in two builds (one 1024-thread workgroup with 8192 table slots per
+    CU, two 512-thread workgroups with 4096); the host picks one per launch.  Both give the same
+    clouds, and a chunk the small one cannot hold (10x diffusion: a time bucket with more than 4096
+    keys) is run again with the big one without losing a point."""
+    stats = {}
+    for variant in ("big", "small"):
+        monkeypatch.setenv("ATTPC_SC_VARIANT", variant)
+        fresh = _abi.Context(0)
+        for name, n in (("o16aa", 3000), ("b10chain", 1500)):
+            inp = Inputs(name)
+            eng = _engine(inp, fresh)
+            stats[variant, name] = eng.run(n, seed=5, first_event=11)["stats"]
+        fresh.close()
+    for name in ("o16aa", "b10chain"):
+        a, b = stats["big", name], stats["small", name]
+        for k in ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_failed", "n_inconsistent"):
+            assert a[k] == b[k], (name, k)
+        assert a["n_failed"] == 0 and a["n_inconsistent"] == 0
+    assert stats["small", "b10chain"]["launches_scatter"] >= 1
+
+
 def test_fetch_with_block_reserved_rows(ctx):
     """A launch large enough for block-wise row reservations (holes between the workgroups' blocks):
     the gathered CSR cloud reproduces the device-side checksums, so no row is lost or doubled."""

@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void spyral_rows_kernel(int64_t n, const doubl
                                                           double* __restrict__ rows) {
   __shared__ double resp[ATTPC_NUM_TB];
   for (int i = threadIdx.x; i < ATTPC_NUM_TB; i += 256) resp[i] = response[i];
-  __syncthreads();
+  block_sync();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const double padf = points[3 * i], tb = points[3 * i + 1], q = points[3 * i + 2];

@@ -89,6 +89,17 @@ __device__ __forceinline__ double dedx_lookup(TablePtr tab, double ke) {
   return lo + t * (hi - lo);
 }
 
+// Workgroup barrier with an explicit wait for this wave's own LDS operations.  hipcc places
+// `s_waitcnt lgkmcnt(0)` in front of most `s_barrier`s by itself, but not in front of one at the
+// head of a loop whose back edge carries a `ds_write` (scatter.hip's batch loop: thread 0's write of
+// the next batch index could still be queued when the barrier released the other waves, which then
+// read the OLD index and worked on another event than wave 0).  Never seen with one workgroup per CU;
+// about once per 20 000 windows when two workgroups share a CU and contend for the LDS.
+__device__ __forceinline__ void block_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // ---- device-side views of the configuration (pointers are device pointers) ----
 struct DetDev {
   double length, efield, bfield, density, diffusion, fano_factor, w_value;

@@ -342,17 +342,6 @@ __device__ __forceinline__ int local_const(int value) {
   return value;
 }
 
-// Workgroup barrier with an explicit wait for this wave's own LDS operations.  hipcc places
-// `s_waitcnt lgkmcnt(0)` in front of most `s_barrier`s by itself, but not in front of the one at the
-// head of the batch loop: thread 0's `ds_write` of the next batch index (issued on the loop's back
-// edge) could still be queued when the barrier released the other waves, which then read the OLD index
-// and worked on another event than wave 0.  Never seen with one workgroup per CU; about once per
-// 20 000 windows when two workgroups share a CU and contend for the LDS (found with that build).
-__device__ __forceinline__ void block_sync() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();
-}
-
 __device__ __forceinline__ int fresh_tid() {
   int t = (int)threadIdx.x;
   asm volatile("" : "+v"(t));

@@ -39,13 +39,13 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_count_kernel(SpyralDev sp, 
   __shared__ int total;
   const uint32_t e = blockIdx.x;
   if (threadIdx.x == 0) total = 0;
-  __syncthreads();
+  block_sync();
   const int64_t lo = event_start[e], hi = event_start[e + 1];
   int mine = 0;
   for (int64_t r = lo + threadIdx.x; r < hi; r += SP_THREADS) mine += amplitude(sp, points[3 * r + 2]) > sp.threshold ? 1 : 0;
   for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&total, mine);
-  __syncthreads();
+  block_sync();
   if (threadIdx.x == 0) kept[e] = total;
 }
 
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, 
   const uint32_t e = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) running = 0;
-  __syncthreads();
+  block_sync();
   const int64_t lo = event_start[e], hi = event_start[e + 1];
   const int64_t out0 = kept_start[e];
   for (int64_t r0 = lo; r0 < hi; r0 += SP_THREADS) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, 
     }
     const unsigned long long m = __ballot(keep);
     if (lane == 0) wave_count[wave] = (int)__popcll(m);
-    __syncthreads();
+    block_sync();
     int before = running;
     for (int w = 0; w < wave; ++w) before += wave_count[w];
     if (keep) {
@@ -94,13 +94,13 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, 
       row[7] = sp.pad_sizes[pad];
       out_labels[o] = labels[r];
     }
-    __syncthreads();
+    block_sync();
     if (threadIdx.x == 0) {
       int all = 0;
       for (int w = 0; w < SP_THREADS / 64; ++w) all += wave_count[w];
       running += all;
     }
-    __syncthreads();
+    block_sync();
   }
 }
 

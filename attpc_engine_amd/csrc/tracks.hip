@@ -74,7 +74,7 @@ __global__ __launch_bounds__(TRACK_THREADS) void track_kernel(TrackArgs a) {
   extern __shared__ double lds_tab[];  // [n_species][ATTPC_DEDX_NODES]
   const int n_tab = a.det.n_species * ATTPC_DEDX_NODES;
   for (int i = threadIdx.x; i < n_tab; i += TRACK_THREADS) lds_tab[i] = a.det.dedx[i];
-  __syncthreads();
+  block_sync();
 
   const int lane = threadIdx.x & 63;
   const int nsub = a.det.ode_substeps > 0 ? a.det.ode_substeps : 1;

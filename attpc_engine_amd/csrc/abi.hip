@@ -203,7 +203,10 @@ int32_t run_scatter(attpc_ctx* ctx, const attpc_event_layout& lay, const TrackBu
   // launch geometry: persistent workgroups that take `batch` events per visit to the event counter
   // and reserve output rows `row_block` at a time (small launches: exact reservations, so that short
   // runs waste no rows)
-  uint32_t sc_wgs = std::min<uint32_t>((uint32_t)ctx->n_cus * (use_small ? 2u : 1u), n);
+#ifndef ATTPC_SC_SMALL_WGS
+#define ATTPC_SC_SMALL_WGS 2  // workgroups per CU of the small variant (scatter_small.hip)
+#endif
+  uint32_t sc_wgs = std::min<uint32_t>((uint32_t)ctx->n_cus * (use_small ? (uint32_t)ATTPC_SC_SMALL_WGS : 1u), n);
   uint32_t sc_batch = n / sc_wgs >= 64u ? 2u : 1u;  // the request for the next batch is hidden (scatter.hip)
   const int64_t est_rows = (int64_t)n * 9216;
   uint32_t sc_row_block = est_rows / ((int64_t)sc_wgs * 16) >= 16384

@@ -7,9 +7,10 @@
 // :78-120 (position_to_index: floor to whole mm), pairing.py (key), beam_pads.py (folded
 // into the LUT), simulator.py:19-49 (dict_to_points), :108-113 (tb jitter, 0 <= tb < 512).
 //
-// Execution model: persistent workgroups of 1024 threads, one per compute unit, take events from a
-// global counter; one event at a time, its dictionary is an open-addressing hash table in LDS
-// (u32 key|label word + u64 charge, 8192 slots = 96 KiB, buckets of 4 keys).
+// Execution model: persistent workgroups (1024 threads and 8192 table slots, one per compute unit; or,
+// built through scatter_small.hip, 512 threads and 4096 slots, two per compute unit) take events from
+// a global counter; one event at a time, its dictionary is an open-addressing hash table in LDS
+// (u32 key|label word + u64 charge per slot, buckets of 4 keys).
 // Per event: the entries (samples x slices) are histogrammed by time bucket, prefix-summed and
 // sorted by time bucket once; events with more keys than the table should hold are cut into
 // time-bucket windows (a key contains its time bucket, so windows partition the key space) sized by

@@ -935,7 +935,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
           if (base != ~0ull) {
             const unsigned long long row = base + r;
             double ua, ub;
-            rng_pair(a.seed, event, key, DOMAIN_JITTER, ua, ub);  // simulator.py:108
+            rng_pair<7>(a.seed, event, key, DOMAIN_JITTER, ua, ub);  // simulator.py:108
             double* o = a.out.points + row * 3;
             o[0] = (double)pad;
             o[1] = (double)tb + ua;

@@ -26,11 +26,11 @@ static const double KE_LIMIT = 1e-6; /* detector/solver.py:14 */
 static const double PI = 3.141592653589793;
 
 /* ------------------------------------------------------------------ RNG ---------- */
-/* Philox4x32-10 (Salmon et al., SC'11; the generator behind rocRAND's default). */
-void orc_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4]) {
+/* Philox4x32-R (Salmon et al., SC'11; R = 10 is the generator behind rocRAND's default). */
+void orc_philox4x32(const uint32_t ctr_in[4], const uint32_t key_in[2], int32_t rounds, uint32_t out[4]) {
   uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
   uint32_t k0 = key_in[0], k1 = key_in[1];
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < rounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -44,6 +44,10 @@ void orc_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint3
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+void orc_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4]) {
+  orc_philox4x32(ctr_in, key_in, 10, out);
+}
+
 static double u53(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
@@ -55,6 +59,17 @@ void orc_rng_pair(uint64_t seed, uint64_t event, uint32_t index, uint32_t domain
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
   uint32_t r[4];
   orc_philox4x32_10(ctr, key, r);
+  *u_a = u53(r[0], r[1]);
+  *u_b = u53(r[2], r[3]);
+}
+
+/* the time-bucket jitter (one draw per cloud point, the most numerous random numbers of the path)
+ * uses the 7-round variant: the fewest rounds that pass BigCrush in the Philox paper */
+void orc_rng_pair7(uint64_t seed, uint64_t event, uint32_t index, uint32_t domain, double* u_a, double* u_b) {
+  uint32_t ctr[4] = {(uint32_t)event, (uint32_t)(event >> 32), index, domain};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t r[4];
+  orc_philox4x32(ctr, key, 7, r);
   *u_a = u53(r[0], r[1]);
   *u_b = u53(r[2], r[3]);
 }
@@ -637,7 +652,7 @@ int32_t orc_generate_point_cloud(const orc_det_desc* det, const orc_species_desc
 }
 
 /* detector/simulator.py:52-115 (+ dict_to_points :19-49).  The tb jitter of a point is the
- * Philox uniform with index (tb<<14 | pad) in domain 0x100 of the event. */
+ * Philox4x32-7 uniform with index (tb<<14 | pad) in domain 0x100 of the event. */
 int64_t orc_simulate(const orc_det_desc* det, const orc_event_layout* lay, uint64_t seed, uint64_t event,
                      const double* p4, const double* vertex, int64_t capacity, double* points,
                      int64_t* labels, uint64_t* n_track_samples) {
@@ -658,7 +673,7 @@ int64_t orc_simulate(const orc_det_desc* det, const orc_event_layout* lay, uint6
     double tbf = (double)tb;
     if (tb >= 0 && pad >= 0) {
       double ua, ub;
-      orc_rng_pair(seed, event, (uint32_t)((tb << 14) | pad), 0x100u, &ua, &ub);
+      orc_rng_pair7(seed, event, (uint32_t)((tb << 14) | pad), 0x100u, &ua, &ub);
       tbf += ua; /* simulator.py:108 */
     }
     if (0.0 <= tbf && tbf < (double)ORC_NUM_TB) { /* simulator.py:111-113 */

@@ -38,6 +38,7 @@ def lib() -> C.CDLL:
         build()
     L = C.CDLL(str(LIB_PATH))
     L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.orc_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint32)]
     L.orc_rng_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _dp, _dp]
     L.orc_rng_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     L.orc_rng_normal.restype = C.c_double
@@ -98,11 +99,11 @@ def d(arr):
 
 
 # ------------------------------------------------------------------ convenience -------
-def philox(ctr, key) -> np.ndarray:
+def philox(ctr, key, rounds: int = 10) -> np.ndarray:
     c = (C.c_uint32 * 4)(*[int(v) for v in ctr])
     k = (C.c_uint32 * 2)(*[int(v) for v in key])
     out = (C.c_uint32 * 4)()
-    lib().orc_philox4x32_10(c, k, out)
+    lib().orc_philox4x32(c, k, int(rounds), out)
     return np.array(list(out), dtype=np.uint32)
 
 

@@ -15,8 +15,9 @@
  *     attpc_ctx_destroy.  A ctx is single-threaded; distinct ctxs (one per GPU,
  *     one per process in the multi-GPU bench) are independent.
  *   - all floating point is IEEE binary64 ("f64"), charges are int64.
- *   - random numbers: Philox4x32-10, key = seed, counter = (global event id,
- *     draw index, domain) -- results do not depend on batch/chunk/GPU count.
+ *   - random numbers: Philox4x32-10 (Philox4x32-7 for the time-bucket jitter of the
+ *     cloud points), key = seed, counter = (global event id, draw index, domain)
+ *     -- results do not depend on batch/chunk/GPU count.
  */
 #ifndef ATTPC_ENGINE_H
 #define ATTPC_ENGINE_H

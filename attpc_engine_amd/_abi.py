@@ -27,7 +27,9 @@ LONG_STEPS = 5
 EX_GAUSSIAN, EX_UNIFORM, EX_TABLE = 0, 1, 2
 POLAR_UNIFORM, POLAR_ARBITRARY = 0, 1
 
-OK, E_INVALID, E_NODEVICE, E_HIP, E_CAPACITY, E_NOTCONFIGURED = 0, 1, 2, 3, 4, 5
+ABI_VERSION = 2  # ATTPC_ABI_VERSION of include/attpc_engine.h this binding was written against
+
+OK, E_INVALID, E_NODEVICE, E_HIP, E_CAPACITY, E_NOTCONFIGURED, E_DATALOSS = 0, 1, 2, 3, 4, 5, 6
 
 _dp = C.POINTER(C.c_double)
 
@@ -80,6 +82,7 @@ class DetDesc(C.Structure):
         ("long_weights", C.c_double * 5),
         ("mc_diffusion", C.c_int32),
         ("reserved_ext", C.c_int32),
+        ("path_step", C.c_double),
     ]
 
 
@@ -97,6 +100,7 @@ class CloudOut(C.Structure):
         ("offsets", C.POINTER(C.c_int64)),
         ("points", _dp),
         ("labels", C.POINTER(C.c_int64)),
+        ("event_points", C.POINTER(C.c_int64)),
     ]
 
 
@@ -117,6 +121,7 @@ class RunStats(C.Structure):
         ("ms_kinematics", C.c_double), ("ms_tracks", C.c_double), ("ms_scatter", C.c_double),
         ("launches_kinematics", C.c_uint32), ("launches_tracks", C.c_uint32),
         ("launches_scatter", C.c_uint32), ("n_inconsistent", C.c_uint32),
+        ("n_lone_buckets", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:
@@ -125,6 +130,11 @@ class RunStats(C.Structure):
 
 class EngineUnavailable(RuntimeError):
     """The HIP library or a HIP device is missing -- there is no CPU fallback."""
+
+
+class DataLossError(RuntimeError):
+    """A run finished but part of an event's charge is missing from its cloud
+    (``stats.n_failed`` / ``stats.n_inconsistent`` != 0, status ATTPC_E_DATALOSS)."""
 
 
 def dptr(arr: np.ndarray | None):
@@ -154,6 +164,7 @@ EXPORTED_SYMBOLS = (
     "attpc_last_error", "attpc_set_chunk_events", "attpc_sync", "attpc_kin_configure",
     "attpc_kin_run", "attpc_kin_calculate", "attpc_decay_calculate", "attpc_det_configure", "attpc_det_run",
     "attpc_sim_run", "attpc_det_tracks", "attpc_spyral_rows", "attpc_spyral_configure", "attpc_sim_run_spyral",
+    "attpc_set_option", "attpc_host_alloc", "attpc_host_free", "attpc_det_scatter",
 )
 
 _lib = None
@@ -174,6 +185,10 @@ def load_library() -> C.CDLL:
     lib = C.CDLL(str(path))
     ctxp = C.c_void_p
     lib.attpc_version.restype = C.c_int32
+    if lib.attpc_version() != ABI_VERSION:
+        raise EngineUnavailable(
+            f"{path} implements ABI version {lib.attpc_version()}, this package needs {ABI_VERSION}: rebuild it "
+            "(`python -c 'import __graft_entry__ as g; g.build(force=True)'`)")
     lib.attpc_device_count.restype = C.c_int32
     lib.attpc_ctx_create.argtypes = [C.c_int32, C.POINTER(ctxp)]
     lib.attpc_ctx_destroy.argtypes = [ctxp]
@@ -207,6 +222,13 @@ def load_library() -> C.CDLL:
         ctxp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(EventLayout), _dp, _dp, C.c_int64,
         _dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
     ]
+    lib.attpc_det_scatter.argtypes = [
+        ctxp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(EventLayout), _dp, C.POINTER(C.c_int32),
+        C.POINTER(CloudOut), C.POINTER(RunStats),
+    ]
+    lib.attpc_set_option.argtypes = [ctxp, C.c_char_p, C.c_int64]
+    lib.attpc_host_alloc.argtypes = [ctxp, C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.attpc_host_free.argtypes = [ctxp, C.c_void_p]
     lib.attpc_spyral_rows.argtypes = [
         ctxp, C.c_int64, _dp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _dp,
     ]
@@ -244,7 +266,36 @@ class Context:
                 raise BufferError(f"{what}: output capacity too small ({text})")
             if status == E_INVALID:
                 raise ValueError(f"{what}: {text}")
+            if status == E_DATALOSS:
+                raise DataLossError(f"{what}: {text}")
             raise RuntimeError(f"{what} failed with status {status}: {text}")
+
+    def set_option(self, name: str, value: int) -> None:
+        """Tuning / test switches of the context (``attpc_set_option``)."""
+        self.check(self.lib.attpc_set_option(self.handle, name.encode(), int(value)), f"attpc_set_option({name})")
+
+    def pinned_empty(self, shape, dtype=np.float64) -> np.ndarray:
+        """Uninitialised numpy array in page-locked host memory (``attpc_host_alloc``): device-to-host
+        copies into it run at the PCIe rate.  The memory is returned when the array (and every view of
+        it) is garbage collected, or with the context."""
+        import weakref
+
+        dtype = np.dtype(dtype)
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        n_bytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        ptr = C.c_void_p()
+        self.check(self.lib.attpc_host_alloc(self.handle, max(1, n_bytes), C.byref(ptr)), "attpc_host_alloc")
+        raw = (C.c_char * max(1, n_bytes)).from_address(ptr.value)
+        arr = np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+        lib, handle_ref, address = self.lib, weakref.ref(self), ptr.value
+
+        def release():
+            ctx = handle_ref()
+            if ctx is not None and getattr(ctx, "handle", None):
+                lib.attpc_host_free(ctx.handle, C.c_void_p(address))
+
+        weakref.finalize(raw, release)
+        return arr
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -1,13 +1,25 @@
-// abi.hip -- host side of the C ABI (include/attpc_engine.h): context, configuration upload,
-// chunked launch sequence kinematics -> tracks -> scatter on one HIP stream, output assembly.
+// abi.hip -- host side of the C ABI (include/attpc_engine.h): context, configuration upload, the
+// launch pipeline kinematics -> tracks -> scatter (-> Spyral rows) and output assembly.
 //
-// HBM layout per chunk of C events (N rows/event, S simulated nuclei/event, T = C*S tracks):
-//   p4 f64[C][N][4], vertex f64[C][3], status i32[C], attempts u32[C]        kinematics
-//   arena f64[blocks][128][4]  (x, y, time bucket, electrons)                 track samples
-//   block_table i32[T][79], counts i32[T], n_steps i32[T]                     track index
-//   points f64[cap][3], labels i64[cap], segments {event,count,offset}[..]    point cloud
-// Buffers grow on demand and are reused by every chunk (device-resident mode overwrites them).
+// HBM layout (N rows/event, S simulated nuclei/event):
+//   two TRACK SETS, each for one track batch of B events (up to 8 scatter chunks, T = B*S tracks):
+//     p4 f64[B][N][4], vertex f64[B][3], status i32[B], attempts u32[B]          kinematics
+//     arena f64[blocks][128][4]  (x, y, time bucket, electrons)                   track samples
+//     block_table i32[T][79], counts i32[T], n_steps i32[T]                       track index
+//   one CLOUD of one scatter chunk of C events:
+//     points f64[cap][3], labels i64[cap], segments {event,count,offset,ev_offset}[..], ev_rows u32[C]
+//   two ASSEMBLY SETS (only when clouds are delivered to the host): the chunk's cloud in event order
+//     (CSR) or its Spyral rows, filled on the device while the previous chunk's set crosses PCIe.
+// Buffers grow on demand and are reused (device-resident mode overwrites the cloud chunk by chunk).
+//
+// Streams: S (scatter, lone buckets, assembly), T (kinematics + tracks of the NEXT batch, low
+// priority: it fills the compute units the persistent scatter workgroups leave at the end of each
+// launch), C (device-to-host copies).  The host does not wait per launch: control words of every
+// launch are copied to pinned host memory behind it and read once per batch (device-resident) or per
+// chunk (delivered clouds, where the copy needs the row total anyway).  A launch whose buffers
+// turned out too small is repeated with larger ones (results are deterministic, so a re-run is exact).
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -21,20 +33,46 @@ namespace {
 
 using namespace attpc;
 
+constexpr int MAX_SLOTS = 8;           // scatter chunks per track batch
+constexpr int CTRL_WORDS = 32;         // u64 control words per scatter launch (scatter.hip)
+constexpr uint32_t LONE_CAPACITY = 65536;
+constexpr int64_t CLOUD_BUDGET_BYTES = 24ll << 30;  // points + labels of one chunk
+constexpr uint64_t ARENA_BUDGET_BYTES = 24ull << 30;
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+};
+
+struct TrackSet {  // kinematics + tracks of one track batch
+  DevBuf p4, vertex, status, attempts, arena, block_table, counts, n_steps, ctrl;
+  size_t arena_blocks = 0;
+  uint32_t* h_ctrl = nullptr;  // pinned [16]
+  hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr, t0 = nullptr, t1 = nullptr;
+  bool timed_kin = false;
+};
+
+struct AsmSet {  // one chunk's cloud in event order, or its Spyral rows
+  DevBuf ev_start, points, labels, kept, kept_start, sp_rows, sp_labels;
+  int64_t* h_start = nullptr;  // pinned [h_start_len]: CSR offsets of the chunk (n + 1 entries)
+  size_t h_start_len = 0;
+  uint32_t* h_ev_rows = nullptr;  // pinned [h_start_len]: cloud rows of every event before any threshold
+  int64_t* h_total = nullptr;  // pinned [2]: rows in points / sp_rows
+  hipEvent_t ready = nullptr, copied = nullptr;
 };
 
 }  // namespace
 
 struct attpc_ctx {
   int device = 0;
-  int n_cus = 256;                 // compute units (one scatter workgroup each)
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int n_cus = 256;                 // compute units
+  hipStream_t stream = nullptr;    // S
+  hipStream_t stream_t = nullptr;  // T
+  hipStream_t stream_c = nullptr;  // C
   std::string error;
   int32_t chunk_events = 65536;
+  int opt_variant = 0;             // 0 auto, 1 small, 2 big
+  bool opt_tiny = false;
 
   bool kin_ready = false;
   attpc_kin_desc kin{};            // device pointers inside
@@ -44,18 +82,25 @@ struct attpc_ctx {
   DetDev det{};
   std::vector<void*> det_allocs;
 
-  // chunk buffers
-  DevBuf p4, vertex, status, attempts;
-  DevBuf arena, block_table, counts, n_steps, trk_ctrl;
-  DevBuf points, labels, segments, out_ctrl, asm_labels;
+  TrackSet tset[2];
+  // cloud of one chunk
+  DevBuf points, labels, segments, ev_rows, lone_list, out_ctrl;
+  unsigned long long* h_out_ctrl = nullptr;  // pinned [MAX_SLOTS][CTRL_WORDS]
+  hipEvent_t s0[MAX_SLOTS] = {}, s1[MAX_SLOTS] = {};
+  int64_t cloud_capacity = 0, seg_capacity = 0;
+  AsmSet aset[2];
+  DevBuf sort_idx, sort_key;
+  // running estimates that size the next launches (reset by configure)
+  double rows_per_event = 0.0;     // observed cloud rows per event, 0 = unknown
+  double segs_per_event = 0.0;
+  double blocks_per_track = 0.0;   // observed arena blocks per track
+  bool prefer_big = false;         // sticky: the small scatter variant met too many lone buckets
 
   bool spyral_ready = false;
   SpyralDev spyral{};
   std::vector<void*> spyral_allocs;
-  DevBuf sp_rows, sp_labels, sp_event_start, sp_kept, sp_kept_start;
   DevBuf scratch[8];
-  size_t arena_blocks = 0;
-  int64_t cloud_capacity = 0, seg_capacity = 0;
+  std::vector<void*> host_allocs;  // attpc_host_alloc
 };
 
 namespace {
@@ -78,6 +123,7 @@ int32_t fail(attpc_ctx* ctx, int32_t code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                         \
   } while (0)
 
+// grow-only device buffer; the caller makes sure nothing in flight uses it when it has to grow
 int32_t ensure(attpc_ctx* ctx, DevBuf& b, size_t bytes) {
   if (bytes <= b.bytes) return ATTPC_OK;
   if (b.p) HIP_TRY(ctx, hipFree(b.p));
@@ -103,322 +149,654 @@ void free_all(std::vector<void*>& v) {
   v.clear();
 }
 
-int32_t validate_layout(attpc_ctx* ctx, const attpc_event_layout* lay) {
+int32_t sync_all(attpc_ctx* ctx) {
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_t));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
+  return ATTPC_OK;
+}
+
+int32_t validate_layout(attpc_ctx* ctx, const attpc_event_layout* lay, bool with_species) {
   if (!lay || lay->n_rows < 1 || lay->n_rows > ATTPC_MAX_ROWS || lay->n_sim < 0 || lay->n_sim > ATTPC_MAX_SIM)
     return fail(ctx, ATTPC_E_INVALID, "bad event layout");
   for (int i = 0; i < lay->n_sim; ++i) {
     const int row = lay->indices[i];
     if (row < 0 || row >= lay->n_rows) return fail(ctx, ATTPC_E_INVALID, "indices[%d]=%d out of range", i, row);
     const int sp = lay->species_of_row[row];
-    if (sp >= ctx->det.n_species) return fail(ctx, ATTPC_E_INVALID, "species_of_row[%d]=%d out of range", row, sp);
+    if (with_species && sp >= ctx->det.n_species) return fail(ctx, ATTPC_E_INVALID, "species_of_row[%d]=%d out of range", row, sp);
   }
   return ATTPC_OK;
 }
 
 struct ChunkResult {
-  unsigned long long rows = 0, segs = 0, charge = 0, keys = 0, failed = 0, retried = 0, samples = 0, mismatch = 0;
-  float ms_tracks = 0, ms_scatter = 0;
+  unsigned long long rows = 0, reserved = 0, segs = 0, charge = 0, keys = 0, failed = 0, retried = 0, samples = 0,
+                     mismatch = 0, lone = 0;
+  bool overflow = false;
+  float ms_scatter = 0;
 };
 
-// Track integration for a BATCH of `n` events whose kinematics already sit in ctx->p4 / vertex
-// (/status).  A batch spans several scatter chunks: the track kernel hands tracks to lanes
-// dynamically, and with fewer tracks than a few times the 200 k lanes of the chip the launch is one
-// generation of tracks whose length is set by its longest member.
-int32_t run_tracks(attpc_ctx* ctx, const attpc_event_layout& lay, uint64_t seed, uint64_t first_event, uint32_t n,
-                   bool use_status, TrackBuffers* out_buf, double* ms) {
-  const uint32_t n_tracks = n * (uint32_t)lay.n_sim;
-  *out_buf = TrackBuffers{};
-  if (n_tracks == 0) return ATTPC_OK;
-  int32_t rc;
-  if ((rc = ensure(ctx, ctx->block_table, (size_t)n_tracks * MAX_BLOCKS_PER_TRACK * sizeof(int32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->counts, (size_t)n_tracks * sizeof(int32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->n_steps, (size_t)n_tracks * sizeof(int32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->trk_ctrl, 16 * sizeof(uint32_t)))) return rc;
-  const size_t lds = (size_t)ctx->det.n_species * ATTPC_DEDX_NODES * sizeof(double);
-  const uint32_t waves_needed = (n_tracks + 63) / 64;
-  const uint32_t blocks = std::min<uint32_t>((waves_needed + 3) / 4, (uint32_t)ctx->n_cus * 8u);
-  // every wave reserves arena blocks 64 at a time: that slack comes on top of what the samples need
-  size_t want_blocks = std::max<size_t>(ctx->arena_blocks, (size_t)n_tracks * 3 + (size_t)blocks * 4 * 64 + 1024);
-  if (std::getenv("ATTPC_TEST_TINY_BUFFERS") && ctx->arena_blocks == 0) want_blocks = 4;  // test hook: grow-and-rerun path
-
-  for (int attempt = 0; attempt < 8; ++attempt) {
-    if ((rc = ensure(ctx, ctx->arena, want_blocks * ARENA_BLK * 4 * sizeof(double)))) return rc;
-    ctx->arena_blocks = want_blocks;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->trk_ctrl.p, 0, 16 * sizeof(uint32_t), ctx->stream));
-    TrackArgs ta;
-    ta.det = ctx->det;
-    ta.layout = lay;
-    ta.buf.arena = static_cast<double*>(ctx->arena.p);
-    ta.buf.block_table = static_cast<int32_t*>(ctx->block_table.p);
-    ta.buf.counts = static_cast<int32_t*>(ctx->counts.p);
-    ta.buf.n_steps = static_cast<int32_t*>(ctx->n_steps.p);
-    ta.buf.ctrl = static_cast<uint32_t*>(ctx->trk_ctrl.p);
-    ta.buf.arena_blocks = (uint32_t)std::min<size_t>(want_blocks, 0xFFFFFFFFu);
-    ta.p4 = static_cast<const double*>(ctx->p4.p);
-    ta.vertex = static_cast<const double*>(ctx->vertex.p);
-    ta.kin_status = use_status ? static_cast<const int32_t*>(ctx->status.p) : nullptr;
-    ta.seed = seed;
-    ta.first_event = first_event;
-    ta.n_events = n;
-    ta.n_tracks = n_tracks;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    launch_track_kernel(blocks, lds, ctx->stream, ta);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    uint32_t tctrl[4];
-    HIP_TRY(ctx, hipMemcpyAsync(tctrl, ctx->trk_ctrl.p, sizeof tctrl, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    float ms_t = 0;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms_t, ctx->ev[0], ctx->ev[1]));
-    *ms += ms_t;  // timings of discarded attempts stay counted: they were spent
-    if (tctrl[2] == 0) {  // no sample was refused
-      *out_buf = ta.buf;
-      return ATTPC_OK;
+// ------------------------------------------------------------------ small device helpers ----
+// out[i] = sum of in[0..i), i = 0..n (one workgroup; n is a chunk's event count), *total = out[n]
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint32_t* __restrict__ in, uint32_t n,
+                                                              int64_t* __restrict__ out, int64_t* __restrict__ total) {
+  __shared__ long long wave_sum[16];
+  __shared__ long long carry;
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) carry = 0;
+  block_sync();
+  for (uint32_t base = 0; base < n; base += 1024u) {
+    const uint32_t i = base + (uint32_t)t;
+    const long long v = i < n ? (long long)in[i] : 0ll;
+    long long incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const long long up = __shfl_up(incl, off);
+      incl += lane >= off ? up : 0ll;
     }
-    want_blocks = std::max<size_t>((size_t)tctrl[1] + 1024, want_blocks * 2);  // arena exhausted
+    if (lane == 63) wave_sum[wave] = incl;
+    block_sync();
+    long long before = carry;
+    for (int w = 0; w < wave; ++w) before += wave_sum[w];
+    if (i < n) out[i] = before + incl - v;
+    block_sync();
+    if (t == 1023) carry = before + incl;
+    block_sync();
   }
-  return fail(ctx, ATTPC_E_HIP, "track arena did not fit after repeated growth");
+  if (t == 0) {
+    out[n] = carry;
+    if (total) *total = carry;
+  }
 }
 
-// Scatter for the `n` events starting at event `e0` of the current track batch (global id
-// `first_event` = batch first + e0).
-int32_t run_scatter(attpc_ctx* ctx, const attpc_event_layout& lay, const TrackBuffers& trk, uint64_t seed,
-                    uint64_t first_event, uint32_t e0, uint32_t n, ChunkResult* res) {
-  if (n == 0 || lay.n_sim == 0) {
-    *res = ChunkResult{};
-    return ATTPC_OK;
-  }
-  int32_t rc;
-  if ((rc = ensure(ctx, ctx->out_ctrl, 32 * sizeof(unsigned long long)))) return rc;
-  // Kernel variant: "small" (two 512-thread workgroups with 4096-slot tables per CU) is ~6 % faster
-  // for detectors with the usual diffusion; "big" (one 1024-thread workgroup, 8192 slots) holds twice
-  // as many keys per time bucket.  Small is used when a sample is expected to touch at most 40 pads at
-  // the far end of the drift (default detector: 28; the same estimate as key_estimate() in scatter.hip)
-  // and no extension is on; if a launch of the small variant meets a time bucket that does not fit
-  // (n_failed), the chunk is simply run again with the big one (results are deterministic).
-  const double spread = (6.0 / 4.9e-3) * (6.0 / 4.9e-3) * 2.0 * ctx->det.diffusion * ctx->det.dv / ctx->det.efield;
-  const double far_keys = (1.0 + std::sqrt(spread * (ATTPC_NUM_TB - 1))) * (1.0 + std::sqrt(spread * (ATTPC_NUM_TB - 1)));
-  bool use_small = far_keys <= 40.0 && !ctx->det.mc_diffusion && !(ctx->det.longitudinal_diffusion > 0.0);
-  if (const char* force = std::getenv("ATTPC_SC_VARIANT")) use_small = std::string(force) == "small";  // tests
-  // launch geometry: persistent workgroups that take `batch` events per visit to the event counter
-  // and reserve output rows `row_block` at a time (small launches: exact reservations, so that short
-  // runs waste no rows)
-#ifndef ATTPC_SC_SMALL_WGS
-#define ATTPC_SC_SMALL_WGS 2  // workgroups per CU of the small variant (scatter_small.hip)
-#endif
-  uint32_t sc_wgs = std::min<uint32_t>((uint32_t)ctx->n_cus * (use_small ? (uint32_t)ATTPC_SC_SMALL_WGS : 1u), n);
-  uint32_t sc_batch = n / sc_wgs >= 64u ? 2u : 1u;  // the request for the next batch is hidden (scatter.hip)
-  const int64_t est_rows = (int64_t)n * 9216;
-  uint32_t sc_row_block = est_rows / ((int64_t)sc_wgs * 16) >= 16384
-                              ? (uint32_t)std::min<int64_t>(est_rows / ((int64_t)sc_wgs * 16), 1 << 18) : 1u;
-  const int64_t hole_rows = sc_row_block > 1u ? (int64_t)sc_wgs * sc_row_block + est_rows / 16 : 0;
-  int64_t want_rows = std::max<int64_t>(ctx->cloud_capacity, est_rows + hole_rows + 65536);
-  int64_t want_segs = std::max<int64_t>(ctx->seg_capacity, (int64_t)n * 6 + 4096 + (int64_t)sc_wgs * 16);
-  if (std::getenv("ATTPC_TEST_TINY_BUFFERS") && ctx->cloud_capacity == 0) {
-    want_rows = 64;  // test hook: start with buffers that are certainly too small
-    want_segs = 2;
-  }
-
-  for (int attempt = 0; attempt < 9; ++attempt) {
-    if ((rc = ensure(ctx, ctx->points, (size_t)want_rows * 3 * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->labels, (size_t)want_rows * sizeof(int64_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->segments, (size_t)want_segs * sizeof(Segment)))) return rc;
-    ctx->cloud_capacity = want_rows;
-    ctx->seg_capacity = want_segs;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->out_ctrl.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
-    ScatterArgs sa;
-    sa.det = ctx->det;
-    sa.layout = lay;
-    sa.trk = trk;
-    sa.out.points = static_cast<double*>(ctx->points.p);
-    sa.out.labels = static_cast<int64_t*>(ctx->labels.p);
-    sa.out.segments = static_cast<Segment*>(ctx->segments.p);
-    sa.out.ctrl = static_cast<unsigned long long*>(ctx->out_ctrl.p);
-    sa.out.capacity = want_rows;
-    sa.out.seg_capacity = want_segs;
-    sa.seed = seed;
-    sa.first_event = first_event;
-    sa.n_events = n;
-    sa.event0 = e0;
-    sa.batch = sc_batch;
-    sa.row_block = sc_row_block;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    if (use_small) launch_scatter_kernel_small(sc_wgs, ctx->stream, sa);
-    else launch_scatter_kernel_big(sc_wgs, ctx->stream, sa);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    unsigned long long octrl[32];
-    HIP_TRY(ctx, hipMemcpyAsync(octrl, ctx->out_ctrl.p, sizeof octrl, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    float ms_s = 0;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms_s, ctx->ev[2], ctx->ev[3]));
-    res->ms_scatter += ms_s;
-#ifdef ATTPC_PHASE_TIMERS
-    fprintf(stderr, "[attpc phase cycles] init %llu hist %llu select %llu stage %llu items %llu overflow %llu flushcount %llu flushwrite %llu (events %u)\n",
-            octrl[8], octrl[9], octrl[10], octrl[11], octrl[12], octrl[13], octrl[14], octrl[15], n);
-    fprintf(stderr, "[attpc rows-phase cycles] gathers %llu runs %llu scan+queue %llu drain %llu\n", octrl[16], octrl[17], octrl[18], octrl[19]);
-    fprintf(stderr, "[attpc rounds] rows-rounds %llu staged %llu busiest-wave passes %llu\n", octrl[20], octrl[21], octrl[22]);
-    fprintf(stderr, "[attpc flush cycles] to-barrier %llu to-compacted %llu atomics-wait %llu segment %llu select %llu barrier %llu\n", octrl[27], octrl[23], octrl[24], octrl[25], octrl[26], octrl[14]);
-    fprintf(stderr, "[attpc ctrl] rows %llu segments %llu failed %llu retried %llu samples %llu\n", octrl[0], octrl[1],
-            octrl[4], octrl[5], octrl[7]);
-#endif
-    if (use_small && octrl[4] != 0) {  // a time bucket with more keys than the small table: run the chunk with the big one
-      use_small = false;
-      sc_wgs = std::min<uint32_t>((uint32_t)ctx->n_cus, n);
-      sc_batch = n / sc_wgs >= 64u ? 2u : 1u;
-      sc_row_block = est_rows / ((int64_t)sc_wgs * 16) >= 16384 ? (uint32_t)std::min<int64_t>(est_rows / ((int64_t)sc_wgs * 16), 1 << 18) : 1u;
-      continue;
-    }
-    if (octrl[6] == 0) {
-      res->rows = octrl[30];  // rows written; octrl[0] is the reservation cursor (holes included)
-      res->segs = octrl[1];
-      res->charge = octrl[2];
-      res->keys = octrl[3];
-      res->failed = octrl[4];
-      res->retried = octrl[5];
-      res->samples = octrl[7];
-      res->mismatch = octrl[31];
-      return ATTPC_OK;
-    }
-    // cloud / segment capacity exceeded (the cursors kept counting)
-    want_rows = std::max<int64_t>(want_rows, (int64_t)(octrl[0] + octrl[0] / 8) + 65536);
-    want_segs = std::max<int64_t>(want_segs, (int64_t)(octrl[1] + octrl[1] / 8) + 4096);
-  }
-  return fail(ctx, ATTPC_E_HIP, "point cloud did not fit after repeated buffer growth");
-}
-
-// events per track batch: several scatter chunks, bounded so that the sample arena stays below ~24 GB
-uint64_t track_batch_events(const attpc_ctx* ctx, const attpc_event_layout& lay) {
-  const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events);
-  const uint64_t by_memory = (24ull << 30) / ((uint64_t)std::max(1, lay.n_sim) * 3ull * ARENA_BLK * 4 * sizeof(double));
-  const uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>(8, by_memory / chunk));
-  return chunk * chunks;
-}
-
-// Device-side CSR assembly: segment s (one flushed window of one event) is copied to row
-// dst[s] of the event-ordered arrays, so the host receives one contiguous block per chunk.
+// Device-side CSR assembly: segment s (one flushed window of one event) is copied to rows
+// ev_start[event] + ev_offset of the event-ordered arrays.  n_segs is read from the launch's control
+// words (the host never sees the segment list).
 __global__ __launch_bounds__(256) void gather_segments_kernel(const Segment* __restrict__ segs,
-                                                              const int64_t* __restrict__ dst, uint32_t n_segs,
+                                                              const unsigned long long* __restrict__ ctrl,
+                                                              int64_t seg_capacity,
+                                                              const int64_t* __restrict__ ev_start,
                                                               const double* __restrict__ points,
                                                               const int64_t* __restrict__ labels,
                                                               double* __restrict__ out_points,
                                                               int64_t* __restrict__ out_labels) {
+  const unsigned long long n_all = ctrl[1];
+  const uint32_t n_segs = (uint32_t)(n_all < (unsigned long long)seg_capacity ? n_all : (unsigned long long)seg_capacity);
   for (uint32_t s = blockIdx.x; s < n_segs; s += gridDim.x) {
     const Segment sg = segs[s];
+    if (sg.count <= 0) continue;
+    const int64_t dst = ev_start[sg.event] + sg.ev_offset;
     const double* src_p = points + sg.offset * 3;
-    double* dst_p = out_points + dst[s] * 3;
+    double* dst_p = out_points + dst * 3;
     for (int i = threadIdx.x; i < sg.count * 3; i += 256) dst_p[i] = src_p[i];
     const int64_t* src_l = labels + sg.offset;
-    int64_t* dst_l = out_labels + dst[s];
+    int64_t* dst_l = out_labels + dst;
     for (int i = threadIdx.x; i < sg.count; i += 256) dst_l[i] = src_l[i];
   }
 }
 
-// Event-ordered (CSR) copy of one chunk's cloud on the device: scratch[7] = points, asm_labels =
-// labels; `start` receives the chunk-local row offset of every event (n + 1 entries).
-int32_t gather_chunk_csr(attpc_ctx* ctx, const ChunkResult& r, uint32_t n, std::vector<int64_t>* start, bool run_gather) {
-  std::vector<Segment> segs(r.segs);
-  if (r.segs) HIP_TRY(ctx, hipMemcpy(segs.data(), ctx->segments.p, r.segs * sizeof(Segment), hipMemcpyDeviceToHost));
-  std::vector<int64_t> counts(n, 0);
-  for (const Segment& s : segs) counts[s.event] += s.count;
-  start->assign(n + 1, 0);
-  for (uint32_t i = 0; i < n; ++i) (*start)[i + 1] = (*start)[i] + counts[i];
-  if (!run_gather || r.rows == 0) return ATTPC_OK;
-  std::vector<int64_t> dst(r.segs);
-  std::vector<int64_t> fill(start->begin(), start->end() - 1);
-  for (size_t s = 0; s < segs.size(); ++s) {  // segments of one event appear in window order
-    dst[s] = fill[segs[s].event];
-    fill[segs[s].event] += segs[s].count;
-  }
+__global__ __launch_bounds__(256) void count_status_kernel(const int32_t* __restrict__ status, uint32_t n,
+                                                           uint32_t* __restrict__ counter) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const bool bad = i < n && status[i] != 0;
+  const unsigned long long m = __ballot(bad);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (uint32_t)__popcll(m));
+}
+
+// ------------------------------------------------------------------ tracks ----
+int32_t ensure_kin_buffers(attpc_ctx* ctx, TrackSet& ts, uint32_t n, int n_rows) {
   int32_t rc;
-  if ((rc = ensure(ctx, ctx->scratch[6], r.segs * sizeof(int64_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->scratch[7], (size_t)r.rows * 3 * sizeof(double)))) return rc;
-  if ((rc = ensure(ctx, ctx->asm_labels, (size_t)r.rows * sizeof(int64_t)))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch[6].p, dst.data(), r.segs * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)std::min<uint64_t>(r.segs, 65535)), dim3(256), 0,
-                     ctx->stream, static_cast<const Segment*>(ctx->segments.p),
-                     static_cast<const int64_t*>(ctx->scratch[6].p), (uint32_t)r.segs,
-                     static_cast<const double*>(ctx->points.p), static_cast<const int64_t*>(ctx->labels.p),
-                     static_cast<double*>(ctx->scratch[7].p), static_cast<int64_t*>(ctx->asm_labels.p));
-  HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // dst is a local vector
+  if ((rc = ensure(ctx, ts.p4, (size_t)n * n_rows * 4 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ts.vertex, (size_t)n * 3 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ts.status, (size_t)n * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(ctx, ts.attempts, (size_t)n * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ts.ctrl, 16 * sizeof(uint32_t)))) return rc;
   return ATTPC_OK;
 }
 
-// copy one chunk's cloud to the caller's CSR arrays (events in order)
-int32_t assemble_chunk(attpc_ctx* ctx, const ChunkResult& r, uint32_t n, uint64_t chunk_first_local,
-                       attpc_cloud_out* out, int64_t* row_cursor, bool* over_capacity) {
-  const int64_t base = *row_cursor;
-  const bool fits = out->points && out->labels && base + (int64_t)r.rows <= out->capacity;
-  std::vector<int64_t> start;
-  int32_t rc = gather_chunk_csr(ctx, r, n, &start, fits);
-  if (rc) return rc;
-  if (out->offsets)
-    for (uint32_t i = 0; i <= n; ++i) out->offsets[chunk_first_local + i] = base + start[i];
-  *row_cursor = base + start[n];
-  if (!fits) {
-    if (*row_cursor > out->capacity) *over_capacity = true;
-    return ATTPC_OK;
-  }
-  if (r.rows == 0) return ATTPC_OK;
-  HIP_TRY(ctx, hipMemcpyAsync(out->points + base * 3, ctx->scratch[7].p, (size_t)r.rows * 3 * sizeof(double),
-                              hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(out->labels + base, ctx->asm_labels.p, (size_t)r.rows * sizeof(int64_t),
-                              hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return ATTPC_OK;
-}
+struct TrackLaunch {  // what launch_tracks queued, for finish_tracks
+  attpc_event_layout lay{};
+  uint64_t seed = 0, first_event = 0;
+  uint32_t n = 0;
+  bool use_status = false;
+};
 
-// response + threshold + Spyral rows of one chunk on the device, then D2H (rows of 8 doubles)
-int32_t assemble_chunk_spyral(attpc_ctx* ctx, const ChunkResult& r, uint32_t n, uint64_t chunk_first_local,
-                              attpc_cloud_out* out, int64_t* row_cursor, bool* over_capacity) {
-  std::vector<int64_t> start;
-  int32_t rc = gather_chunk_csr(ctx, r, n, &start, true);
-  if (rc) return rc;
-  const int64_t base = *row_cursor;
-  std::vector<int64_t> kept_start(n + 1, 0);
-  if (r.rows) {
-    if ((rc = ensure(ctx, ctx->sp_event_start, (n + 1) * sizeof(int64_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->sp_kept_start, (n + 1) * sizeof(int64_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->sp_kept, n * sizeof(int32_t)))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_event_start.p, start.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    launch_spyral_count(ctx->stream, ctx->spyral, n, static_cast<const int64_t*>(ctx->sp_event_start.p),
-                        static_cast<const double*>(ctx->scratch[7].p), static_cast<int32_t*>(ctx->sp_kept.p));
+// Queue the track integration of a BATCH of `n` events whose kinematics are (being) written to the
+// set's p4 / vertex (/ status) on stream T.  A batch spans several scatter chunks: the track kernel
+// hands tracks to lanes dynamically, and with fewer tracks than a few times the 200 k lanes of the
+// chip the launch is one generation of tracks whose length is set by its longest member.
+int32_t launch_tracks(attpc_ctx* ctx, TrackSet& ts, const TrackLaunch& tl) {
+  const uint32_t n_tracks = tl.n * (uint32_t)tl.lay.n_sim;
+  int32_t rc;
+  if ((rc = ensure(ctx, ts.ctrl, 16 * sizeof(uint32_t)))) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ts.ctrl.p, 0, 16 * sizeof(uint32_t), ctx->stream_t));
+  if (n_tracks) {
+    if ((rc = ensure(ctx, ts.block_table, (size_t)n_tracks * MAX_BLOCKS_PER_TRACK * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ts.counts, (size_t)n_tracks * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ts.n_steps, (size_t)n_tracks * sizeof(int32_t)))) return rc;
+    const size_t lds = (size_t)ctx->det.n_species * ATTPC_DEDX_NODES * sizeof(double);
+    const uint32_t waves_needed = (n_tracks + 63) / 64;
+    const uint32_t blocks = std::min<uint32_t>((waves_needed + 3) / 4, (uint32_t)ctx->n_cus * 8u);
+    // every wave reserves arena blocks 64 at a time: that slack comes on top of what the samples need
+    const double per_track = ctx->blocks_per_track > 0.0 ? ctx->blocks_per_track * 1.15 + 0.25 : 3.0;
+    size_t want_blocks = std::max<size_t>(ts.arena_blocks, (size_t)((double)n_tracks * per_track) + (size_t)blocks * 4 * 64 + 1024);
+    if (ctx->opt_tiny && ts.arena_blocks == 0) want_blocks = 4;  // test hook: grow-and-rerun path
+    if ((rc = ensure(ctx, ts.arena, want_blocks * ARENA_BLK * 4 * sizeof(double)))) return rc;
+    ts.arena_blocks = want_blocks;
+    TrackArgs ta;
+    ta.det = ctx->det;
+    ta.layout = tl.lay;
+    ta.buf.arena = static_cast<double*>(ts.arena.p);
+    ta.buf.block_table = static_cast<int32_t*>(ts.block_table.p);
+    ta.buf.counts = static_cast<int32_t*>(ts.counts.p);
+    ta.buf.n_steps = static_cast<int32_t*>(ts.n_steps.p);
+    ta.buf.ctrl = static_cast<uint32_t*>(ts.ctrl.p);
+    ta.buf.arena_blocks = (uint32_t)std::min<size_t>(want_blocks, 0xFFFFFFFFu);
+    ta.p4 = static_cast<const double*>(ts.p4.p);
+    ta.vertex = static_cast<const double*>(ts.vertex.p);
+    ta.kin_status = tl.use_status ? static_cast<const int32_t*>(ts.status.p) : nullptr;
+    ta.seed = tl.seed;
+    ta.first_event = tl.first_event;
+    ta.n_events = tl.n;
+    ta.n_tracks = n_tracks;
+    HIP_TRY(ctx, hipEventRecord(ts.t0, ctx->stream_t));
+    launch_track_kernel(blocks, lds, ctx->stream_t, ta);
     HIP_TRY(ctx, hipGetLastError());
-    std::vector<int32_t> kept(n);
-    HIP_TRY(ctx, hipMemcpyAsync(kept.data(), ctx->sp_kept.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (uint32_t i = 0; i < n; ++i) kept_start[i + 1] = kept_start[i] + kept[i];
+    HIP_TRY(ctx, hipEventRecord(ts.t1, ctx->stream_t));
   }
-  const int64_t n_kept = kept_start[n];
-  if (out->offsets)
-    for (uint32_t i = 0; i <= n; ++i) out->offsets[chunk_first_local + i] = base + kept_start[i];
-  *row_cursor = base + n_kept;
-  if (*row_cursor > out->capacity || !out->points || !out->labels) {
-    if (*row_cursor > out->capacity) *over_capacity = true;
-    return ATTPC_OK;
+  if (tl.use_status && tl.n) {  // events that hit event_sample_limit -> ctrl[3]
+    hipLaunchKernelGGL(count_status_kernel, dim3((tl.n + 255) / 256), dim3(256), 0, ctx->stream_t,
+                       static_cast<const int32_t*>(ts.status.p), tl.n, static_cast<uint32_t*>(ts.ctrl.p) + 3);
+    HIP_TRY(ctx, hipGetLastError());
   }
-  if (n_kept == 0) return ATTPC_OK;
-  if ((rc = ensure(ctx, ctx->sp_rows, (size_t)n_kept * 8 * sizeof(double)))) return rc;
-  if ((rc = ensure(ctx, ctx->sp_labels, (size_t)n_kept * sizeof(int64_t)))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_kept_start.p, kept_start.data(), (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-  launch_spyral_write(ctx->stream, ctx->spyral, n, static_cast<const int64_t*>(ctx->sp_event_start.p),
-                      static_cast<const int64_t*>(ctx->sp_kept_start.p), static_cast<const double*>(ctx->scratch[7].p),
-                      static_cast<const int64_t*>(ctx->asm_labels.p), static_cast<double*>(ctx->sp_rows.p),
-                      static_cast<int64_t*>(ctx->sp_labels.p));
-  HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipMemcpyAsync(out->points + base * 8, ctx->sp_rows.p, (size_t)n_kept * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(out->labels + base, ctx->sp_labels.p, (size_t)n_kept * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ts.h_ctrl, ts.ctrl.p, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream_t));
+  HIP_TRY(ctx, hipEventRecord(ts.done, ctx->stream_t));
   return ATTPC_OK;
 }
 
-int32_t ensure_kin_buffers(attpc_ctx* ctx, uint32_t n, int n_rows) {
+// Wait for the batch queued by launch_tracks; a batch whose arena was too small is run again with a
+// larger one.  ms / n_limit accumulate.
+int32_t finish_tracks(attpc_ctx* ctx, TrackSet& ts, const TrackLaunch& tl, TrackBuffers* out, double* ms_tracks,
+                      uint64_t* n_limit) {
+  const uint32_t n_tracks = tl.n * (uint32_t)tl.lay.n_sim;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    HIP_TRY(ctx, hipEventSynchronize(ts.done));
+    if (n_tracks) {
+      float ms_t = 0;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms_t, ts.t0, ts.t1));
+      *ms_tracks += ms_t;  // timings of discarded attempts stay counted: they were spent
+    }
+    if (ts.h_ctrl[2] == 0) {  // no sample was refused
+      if (n_tracks) ctx->blocks_per_track = (double)ts.h_ctrl[1] / (double)n_tracks;
+      if (n_limit) *n_limit += ts.h_ctrl[3];
+      *out = TrackBuffers{};
+      out->arena = static_cast<double*>(ts.arena.p);
+      out->block_table = static_cast<int32_t*>(ts.block_table.p);
+      out->counts = static_cast<int32_t*>(ts.counts.p);
+      out->n_steps = static_cast<int32_t*>(ts.n_steps.p);
+      out->ctrl = static_cast<uint32_t*>(ts.ctrl.p);
+      out->arena_blocks = (uint32_t)std::min<size_t>(ts.arena_blocks, 0xFFFFFFFFu);
+      return ATTPC_OK;
+    }
+    // arena exhausted (the block counter kept counting): grow and run the batch again
+    const size_t want = std::max<size_t>((size_t)ts.h_ctrl[1] + (size_t)ts.h_ctrl[1] / 8 + 1024, ts.arena_blocks * 2);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_t));
+    ts.arena_blocks = std::max(ts.arena_blocks, want);
+    int32_t rc = launch_tracks(ctx, ts, tl);
+    if (rc) return rc;
+  }
+  return fail(ctx, ATTPC_E_HIP, "track arena did not fit after repeated growth");
+}
+
+// events per track batch: up to MAX_SLOTS scatter chunks, bounded so that the sample arena stays below
+// ARENA_BUDGET_BYTES (with the observed blocks per track once a batch has run)
+uint64_t track_batch_events(const attpc_ctx* ctx, const attpc_event_layout& lay, uint64_t chunk) {
+  const double per_track = ctx->blocks_per_track > 0.0 ? ctx->blocks_per_track * 1.15 + 0.25 : 3.0;
+  const double bytes_per_event = (double)std::max(1, lay.n_sim) * per_track * ARENA_BLK * 4 * sizeof(double);
+  const uint64_t by_memory = (uint64_t)((double)ARENA_BUDGET_BYTES / bytes_per_event);
+  const uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>(MAX_SLOTS, by_memory / std::max<uint64_t>(1, chunk)));
+  return std::max<uint64_t>(1, std::min<uint64_t>(chunk * chunks, std::max<uint64_t>(by_memory, 1)));
+}
+
+// events of the next scatter chunk: a small pilot while the cloud size per event is unknown, then the
+// configured chunk bounded by the cloud budget
+uint32_t next_chunk_events(const attpc_ctx* ctx, uint64_t remaining) {
+  uint64_t n = (uint64_t)std::max(1, ctx->chunk_events);
+  if (ctx->rows_per_event <= 0.0) n = std::min<uint64_t>(n, 4096);
+  else n = std::min<uint64_t>(n, std::max<uint64_t>(256, (uint64_t)((double)CLOUD_BUDGET_BYTES / (ctx->rows_per_event * 1.15 * 32.0 + 1.0))));
+  return (uint32_t)std::min<uint64_t>(n, remaining);
+}
+
+// ------------------------------------------------------------------ scatter ----
+struct ScatterPlan {  // launch geometry of one chunk
+  bool use_small = false;
+  uint32_t wgs = 0, batch = 1, row_block = 1;
+  int64_t want_rows = 0, want_segs = 0;
+};
+
+ScatterPlan plan_scatter(const attpc_ctx* ctx, uint32_t n) {
+  ScatterPlan p;
+  // Kernel variant: "small" (two 512-thread workgroups with 4096-slot tables per CU) is ~6 % faster
+  // for detectors with the usual diffusion; "big" (one 1024-thread workgroup, 8192 slots) holds twice
+  // as many keys per time bucket.  Small is used when a sample is expected to touch at most 40 pads at
+  // the far end of the drift (default detector: 28; the same estimate as key_estimate() in scatter.hip)
+  // and no extension is on.  A time bucket that fits neither table goes through lone_bucket_kernel; a
+  // context whose small launches meet many of those switches to big for good (prefer_big).
+  const double spread = (6.0 / 4.9e-3) * (6.0 / 4.9e-3) * 2.0 * ctx->det.diffusion * ctx->det.dv / ctx->det.efield;
+  const double far_keys = (1.0 + std::sqrt(spread * (ATTPC_NUM_TB - 1))) * (1.0 + std::sqrt(spread * (ATTPC_NUM_TB - 1)));
+  p.use_small = far_keys <= 40.0 && !ctx->det.mc_diffusion && !(ctx->det.longitudinal_diffusion > 0.0) && !ctx->prefer_big;
+  if (ctx->opt_variant == 1) p.use_small = true;
+  if (ctx->opt_variant == 2) p.use_small = false;
+#ifndef ATTPC_SC_SMALL_WGS
+#define ATTPC_SC_SMALL_WGS 2  // workgroups per CU of the small variant (scatter_small.hip)
+#endif
+  // persistent workgroups that take `batch` events per visit to the event counter and reserve output
+  // rows `row_block` at a time (small launches: exact reservations, so that short runs waste no rows)
+  p.wgs = std::min<uint32_t>((uint32_t)ctx->n_cus * (p.use_small ? (uint32_t)ATTPC_SC_SMALL_WGS : 1u), n);
+  p.batch = n / p.wgs >= 64u ? 2u : 1u;  // the request for the next batch is hidden (scatter.hip)
+  const double per_event = ctx->rows_per_event > 0.0 ? ctx->rows_per_event * 1.10 : 16384.0;
+  const int64_t est_rows = (int64_t)((double)n * per_event) + 4096;
+  p.row_block = est_rows / ((int64_t)p.wgs * 16) >= 16384 ? (uint32_t)std::min<int64_t>(est_rows / ((int64_t)p.wgs * 16), 1 << 18) : 1u;
+  const int64_t hole_rows = p.row_block > 1u ? (int64_t)p.wgs * p.row_block + est_rows / 16 : 0;
+  p.want_rows = est_rows + hole_rows + 65536;
+  const double segs = ctx->segs_per_event > 0.0 ? ctx->segs_per_event * 1.25 + 1.0 : 6.0;
+  p.want_segs = (int64_t)((double)n * segs) + 4096 + (int64_t)p.wgs * 16;
+  if (ctx->opt_tiny && ctx->cloud_capacity == 0) {
+    p.want_rows = 64;  // test hook: start with buffers that are certainly too small
+    p.want_segs = 2;
+  }
+  return p;
+}
+
+// Queue the scatter of the `n` events starting at event `e0` of a track batch (global id
+// `first_event` = batch first + e0) on stream S, control words in slot `slot`.  `grow` may enlarge the
+// cloud (the caller guarantees S is idle then).
+int32_t enqueue_scatter(attpc_ctx* ctx, int slot, const attpc_event_layout& lay, const TrackBuffers& trk, uint64_t seed,
+                        uint64_t first_event, uint32_t e0, uint32_t n, int64_t min_rows, int64_t min_segs) {
   int32_t rc;
-  if ((rc = ensure(ctx, ctx->p4, (size_t)n * n_rows * 4 * sizeof(double)))) return rc;
-  if ((rc = ensure(ctx, ctx->vertex, (size_t)n * 3 * sizeof(double)))) return rc;
-  if ((rc = ensure(ctx, ctx->status, (size_t)n * sizeof(int32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->attempts, (size_t)n * sizeof(uint32_t)))) return rc;
+  const ScatterPlan p = plan_scatter(ctx, n);
+  const int64_t want_rows = std::max<int64_t>({ctx->cloud_capacity, p.want_rows, min_rows});
+  const int64_t want_segs = std::max<int64_t>({ctx->seg_capacity, p.want_segs, min_segs});
+  if (want_rows > ctx->cloud_capacity || want_segs > ctx->seg_capacity || (size_t)n * sizeof(uint32_t) > ctx->ev_rows.bytes) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may use the old buffers
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
+    if ((rc = ensure(ctx, ctx->points, (size_t)want_rows * 3 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->labels, (size_t)want_rows * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->segments, (size_t)want_segs * sizeof(Segment)))) return rc;
+    if ((rc = ensure(ctx, ctx->ev_rows, (size_t)std::max<uint32_t>(n, (uint32_t)std::max(1, ctx->chunk_events)) * sizeof(uint32_t)))) return rc;
+    ctx->cloud_capacity = want_rows;
+    ctx->seg_capacity = want_segs;
+  }
+  unsigned long long* d_ctrl = static_cast<unsigned long long*>(ctx->out_ctrl.p) + (size_t)slot * CTRL_WORDS;
+  HIP_TRY(ctx, hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * sizeof(unsigned long long), ctx->stream));
+  ScatterArgs sa;
+  sa.det = ctx->det;
+  sa.layout = lay;
+  sa.trk = trk;
+  sa.out.points = static_cast<double*>(ctx->points.p);
+  sa.out.labels = static_cast<int64_t*>(ctx->labels.p);
+  sa.out.segments = static_cast<Segment*>(ctx->segments.p);
+  sa.out.ctrl = d_ctrl;
+  sa.out.ev_rows = static_cast<uint32_t*>(ctx->ev_rows.p);
+  sa.out.lone_list = static_cast<LoneBucket*>(ctx->lone_list.p);
+  sa.out.lone_capacity = LONE_CAPACITY;
+  sa.out.capacity = ctx->cloud_capacity;
+  sa.out.seg_capacity = ctx->seg_capacity;
+  sa.seed = seed;
+  sa.first_event = first_event;
+  sa.n_events = n;
+  sa.event0 = e0;
+  sa.batch = p.batch;
+  sa.row_block = p.row_block;
+  HIP_TRY(ctx, hipEventRecord(ctx->s0[slot], ctx->stream));
+  if (p.use_small) launch_scatter_kernel_small(p.wgs, ctx->stream, sa);
+  else launch_scatter_kernel_big(p.wgs, ctx->stream, sa);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->s1[slot], ctx->stream));
+  launch_lone_bucket_kernel(std::min<uint32_t>(64u, (uint32_t)ctx->n_cus), ctx->stream, sa);  // exits at once without lone buckets
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out_ctrl + (size_t)slot * CTRL_WORDS, d_ctrl, CTRL_WORDS * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, ctx->stream));
+#ifdef ATTPC_PHASE_TIMERS
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const unsigned long long* octrl = ctx->h_out_ctrl + (size_t)slot * CTRL_WORDS;
+  fprintf(stderr, "[attpc phase cycles] init %llu hist %llu select %llu stage %llu items %llu overflow %llu flushcount %llu flushwrite %llu (events %u)\n",
+          octrl[8], octrl[9], octrl[10], octrl[11], octrl[12], octrl[13], octrl[14], octrl[15], n);
+  fprintf(stderr, "[attpc rows-phase cycles] gathers %llu runs %llu scan+queue %llu drain %llu\n", octrl[16], octrl[17], octrl[18], octrl[19]);
+  fprintf(stderr, "[attpc rounds] rows-rounds %llu staged %llu busiest-wave passes %llu\n", octrl[20], octrl[21], octrl[22]);
+  fprintf(stderr, "[attpc flush cycles] to-barrier %llu to-compacted %llu atomics-wait %llu segment %llu select %llu barrier %llu\n", octrl[27], octrl[23], octrl[24], octrl[25], octrl[26], octrl[14]);
+  fprintf(stderr, "[attpc ctrl] rows %llu segments %llu failed %llu retried %llu samples %llu\n", octrl[0], octrl[1],
+          octrl[4], octrl[5], octrl[7]);
+#endif
+  return ATTPC_OK;
+}
+
+// Read the control words of slot `slot` (its copy has completed).  Updates the context's size
+// estimates; r->overflow says the launch has to be repeated with at least min_rows / min_segs.
+void read_scatter(attpc_ctx* ctx, int slot, uint32_t n, ChunkResult* r, int64_t* min_rows, int64_t* min_segs) {
+  const unsigned long long* o = ctx->h_out_ctrl + (size_t)slot * CTRL_WORDS;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ctx->s0[slot], ctx->s1[slot]) == hipSuccess) r->ms_scatter += ms;
+  r->overflow = o[6] != 0;
+  r->reserved = o[0];
+  r->segs = o[1];
+  if (r->overflow) {  // cloud / segment capacity exceeded (the cursors kept counting)
+    *min_rows = (int64_t)(o[0] + o[0] / 8) + 65536;
+    *min_segs = (int64_t)(o[1] + o[1] / 8) + 4096;
+    return;
+  }
+  r->rows = o[30];  // rows written; o[0] is the reservation cursor (holes included)
+  r->charge = o[2];
+  r->keys = o[3];
+  r->failed = o[4];
+  r->retried = o[5];
+  r->samples = o[7];
+  r->mismatch = o[31];
+  r->lone = std::min<unsigned long long>(o[29], LONE_CAPACITY);
+  if (n) {
+    ctx->rows_per_event = std::max((double)r->rows / (double)n, 1.0e-3);  // > 0 = known
+    ctx->segs_per_event = (double)r->segs / (double)n;
+    if (r->lone * 100ull > (unsigned long long)n) ctx->prefer_big = true;  // > 1 % of the events: the small table is too small here
+  }
+}
+
+void accumulate(attpc_run_stats* st, const ChunkResult& r) {
+  st->n_points += r.rows;
+  st->n_track_samples += r.samples;
+  st->n_failed += r.failed;
+  st->n_lds_overflow += r.retried;
+  st->charge_checksum += r.charge;
+  st->key_checksum += r.keys;
+  st->ms_scatter += r.ms_scatter;
+  st->launches_scatter += 1;
+  st->n_inconsistent += (uint32_t)r.mismatch;
+  st->n_lone_buckets += r.lone;
+}
+
+// ------------------------------------------------------------------ assembly (delivered clouds) ----
+int32_t ensure_pinned_start(attpc_ctx* ctx, AsmSet& as, size_t len) {
+  if (len <= as.h_start_len) return ATTPC_OK;
+  if (as.h_start) HIP_TRY(ctx, hipHostFree(as.h_start));
+  if (as.h_ev_rows) HIP_TRY(ctx, hipHostFree(as.h_ev_rows));
+  as.h_start = nullptr;
+  as.h_ev_rows = nullptr;
+  as.h_start_len = 0;
+  HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&as.h_start), len * sizeof(int64_t), hipHostMallocDefault));
+  HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&as.h_ev_rows), len * sizeof(uint32_t), hipHostMallocDefault));
+  as.h_start_len = len;
+  return ATTPC_OK;
+}
+
+// Queue, behind the scatter of slot `slot` on S, the assembly of its cloud into `as`: CSR offsets by a
+// device scan of the per-event row counts, rows gathered into event order; for Spyral output also the
+// kept-row counts, their scan and the converted, thresholded, z-sorted rows.  The row totals and the
+// offsets are copied to pinned memory; as.ready is recorded at the end.  `rows_bound` >= the rows the
+// launch can have produced (the reservation capacity).
+int32_t enqueue_assembly(attpc_ctx* ctx, int slot, AsmSet& as, uint32_t n, bool spyral) {
+  int32_t rc;
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, as.copied, 0));  // the set's previous contents have left
+  const size_t cap = (size_t)ctx->cloud_capacity;
+  if ((rc = ensure(ctx, as.ev_start, ((size_t)n + 1) * sizeof(int64_t)))) return rc;
+  if ((rc = ensure(ctx, as.points, cap * 3 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, as.labels, cap * sizeof(int64_t)))) return rc;
+  if ((rc = ensure_pinned_start(ctx, as, (size_t)n + 1))) return rc;
+  const unsigned long long* d_ctrl = static_cast<const unsigned long long*>(ctx->out_ctrl.p) + (size_t)slot * CTRL_WORDS;
+  hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const uint32_t*>(ctx->ev_rows.p), n,
+                     static_cast<int64_t*>(as.ev_start.p), static_cast<int64_t*>(nullptr));
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(gather_segments_kernel, dim3(4096), dim3(256), 0, ctx->stream, static_cast<const Segment*>(ctx->segments.p),
+                     d_ctrl, ctx->seg_capacity, static_cast<const int64_t*>(as.ev_start.p),
+                     static_cast<const double*>(ctx->points.p), static_cast<const int64_t*>(ctx->labels.p),
+                     static_cast<double*>(as.points.p), static_cast<int64_t*>(as.labels.p));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(as.h_ev_rows, ctx->ev_rows.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (!spyral) {
+    HIP_TRY(ctx, hipMemcpyAsync(as.h_start, as.ev_start.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    if ((rc = ensure(ctx, as.kept, (size_t)n * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, as.kept_start, ((size_t)n + 1) * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, as.sp_rows, cap * 8 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, as.sp_labels, cap * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_idx, cap * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_key, cap * sizeof(double)))) return rc;
+    launch_spyral_count(ctx->stream, ctx->spyral, n, static_cast<const int64_t*>(as.ev_start.p),
+                        static_cast<const double*>(as.points.p), static_cast<uint32_t*>(as.kept.p));
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const uint32_t*>(as.kept.p), n,
+                       static_cast<int64_t*>(as.kept_start.p), static_cast<int64_t*>(nullptr));
+    HIP_TRY(ctx, hipGetLastError());
+    launch_spyral_write(ctx->stream, ctx->spyral, n, static_cast<const int64_t*>(as.ev_start.p),
+                        static_cast<const int64_t*>(as.kept_start.p), static_cast<const double*>(as.points.p),
+                        static_cast<const int64_t*>(as.labels.p), static_cast<double*>(as.sp_rows.p),
+                        static_cast<int64_t*>(as.sp_labels.p), static_cast<uint32_t*>(ctx->sort_idx.p),
+                        static_cast<double*>(ctx->sort_key.p));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(as.h_start, as.kept_start.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipEventRecord(as.ready, ctx->stream));
+  return ATTPC_OK;
+}
+
+// The chunk in `as` is ready on the device: write its offsets, queue its copy to the caller's arrays on C.
+int32_t deliver_chunk(attpc_ctx* ctx, AsmSet& as, uint32_t n, uint64_t chunk_first_local, bool spyral, attpc_cloud_out* out,
+                      int64_t* row_cursor, bool* over_capacity) {
+  const int64_t base = *row_cursor;
+  const int64_t total = as.h_start[n];
+  if (out->offsets)
+    for (uint32_t i = 0; i <= n; ++i) out->offsets[chunk_first_local + i] = base + as.h_start[i];
+  if (out->event_points)
+    for (uint32_t i = 0; i < n; ++i) out->event_points[chunk_first_local + i] = (int64_t)as.h_ev_rows[i];
+  *row_cursor = base + total;
+  if (!out->points || !out->labels || *row_cursor > out->capacity) {
+    if (*row_cursor > out->capacity) *over_capacity = true;
+    HIP_TRY(ctx, hipEventRecord(as.copied, ctx->stream_c));
+    return ATTPC_OK;
+  }
+  if (total > 0) {
+    const size_t width = spyral ? 8 : 3;
+    HIP_TRY(ctx, hipMemcpyAsync(out->points + base * width, spyral ? as.sp_rows.p : as.points.p, (size_t)total * width * sizeof(double),
+                                hipMemcpyDeviceToHost, ctx->stream_c));
+    HIP_TRY(ctx, hipMemcpyAsync(out->labels + base, spyral ? as.sp_labels.p : as.labels.p, (size_t)total * sizeof(int64_t),
+                                hipMemcpyDeviceToHost, ctx->stream_c));
+  }
+  HIP_TRY(ctx, hipEventRecord(as.copied, ctx->stream_c));
+  return ATTPC_OK;
+}
+
+// ------------------------------------------------------------------ the run loop ----
+struct RunSource {   // where a batch's kinematics come from
+  bool from_kernel = false;        // attpc_sim_run: kin_run_kernel on T
+  const double* h_p4 = nullptr;    // attpc_det_run: host arrays
+  const double* h_vertex = nullptr;
+};
+
+struct RunSink {     // optional host copies of the kinematics (attpc_sim_run)
+  double* p4 = nullptr;
+  double* vertex = nullptr;
+  int32_t* status = nullptr;
+};
+
+int32_t queue_batch(attpc_ctx* ctx, TrackSet& ts, TrackLaunch& tl, const attpc_event_layout& lay, const RunSource& src,
+                    uint64_t seed, uint64_t first_event, uint64_t b0, uint32_t nb, int n_rows) {
+  int32_t rc;
+  if ((rc = ensure_kin_buffers(ctx, ts, nb, n_rows))) return rc;
+  ts.timed_kin = false;
+  if (src.from_kernel) {
+    HIP_TRY(ctx, hipEventRecord(ts.k0, ctx->stream_t));
+    launch_kin_run(ctx->stream_t, ctx->kin, seed, first_event + b0, nb, static_cast<double*>(ts.p4.p),
+                   static_cast<double*>(ts.vertex.p), static_cast<int32_t*>(ts.status.p), static_cast<uint32_t*>(ts.attempts.p));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ts.k1, ctx->stream_t));
+    ts.timed_kin = true;
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(ts.p4.p, src.h_p4 + b0 * n_rows * 4, (size_t)nb * n_rows * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream_t));
+    HIP_TRY(ctx, hipMemcpyAsync(ts.vertex.p, src.h_vertex + b0 * 3, (size_t)nb * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream_t));
+  }
+  tl.lay = lay;
+  tl.seed = seed;
+  tl.first_event = first_event + b0;
+  tl.n = nb;
+  tl.use_status = src.from_kernel;
+  return launch_tracks(ctx, ts, tl);
+}
+
+// Scatter (and deliver) the chunks of one finished track batch.
+// `queue_next` is called once, right after the first launches of this batch are queued on S: it queues the
+// next batch's kinematics + tracks on the low-priority stream T, BEHIND scatter work, so that the track
+// workgroups only take the compute units the persistent scatter workgroups leave.
+template <typename QueueNext>
+int32_t run_batch_chunks(attpc_ctx* ctx, const attpc_event_layout& lay, const TrackBuffers& trk, uint64_t seed,
+                         uint64_t batch_first_global, uint64_t batch_first_local, uint32_t nb, attpc_cloud_out* out,
+                         bool spyral, attpc_run_stats* st, int64_t* row_cursor, bool* over, QueueNext queue_next) {
+  int32_t rc;
+  bool next_queued = false;
+  auto queue_next_once = [&]() -> int32_t {
+    if (next_queued) return ATTPC_OK;
+    next_queued = true;
+    return queue_next();
+  };
+  if (lay.n_sim == 0 || nb == 0) {  // nothing to scatter: empty clouds
+    if ((rc = queue_next_once())) return rc;
+    if (out && out->offsets)
+      for (uint32_t i = 0; i <= nb; ++i) out->offsets[batch_first_local + i] = *row_cursor;
+    if (out && out->event_points)
+      for (uint32_t i = 0; i < nb; ++i) out->event_points[batch_first_local + i] = 0;
+    return ATTPC_OK;
+  }
+  if ((rc = ensure(ctx, ctx->out_ctrl, (size_t)MAX_SLOTS * CTRL_WORDS * sizeof(unsigned long long)))) return rc;
+  if ((rc = ensure(ctx, ctx->lone_list, (size_t)LONE_CAPACITY * sizeof(LoneBucket)))) return rc;
+  struct Chunk { uint32_t e0, n; int slot; };
+  if (!out) {
+    // device resident: queue up to MAX_SLOTS chunks back to back, read their control words once
+    uint32_t e0 = 0;
+    while (e0 < nb) {
+      std::vector<Chunk> group;
+      while (e0 < nb && (int)group.size() < MAX_SLOTS) {
+        const uint32_t n = next_chunk_events(ctx, nb - e0);
+        const Chunk c{e0, n, (int)group.size()};
+        if ((rc = enqueue_scatter(ctx, c.slot, lay, trk, seed, batch_first_global + e0, e0, n, 0, 0))) return rc;
+        group.push_back(c);
+        e0 += n;
+        if (ctx->rows_per_event <= 0.0) break;  // pilot chunk: size the rest from what it produced
+      }
+      if ((rc = queue_next_once())) return rc;
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      for (const Chunk& c : group) {
+        ChunkResult r;
+        int64_t min_rows = 0, min_segs = 0;
+        read_scatter(ctx, c.slot, c.n, &r, &min_rows, &min_segs);
+        for (int attempt = 0; r.overflow && attempt < 8; ++attempt) {  // too small: run this chunk again
+          if ((rc = enqueue_scatter(ctx, c.slot, lay, trk, seed, batch_first_global + c.e0, c.e0, c.n, min_rows, min_segs))) return rc;
+          HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+          read_scatter(ctx, c.slot, c.n, &r, &min_rows, &min_segs);
+        }
+        if (r.overflow) return fail(ctx, ATTPC_E_HIP, "point cloud did not fit after repeated buffer growth");
+        accumulate(st, r);
+      }
+    }
+    return ATTPC_OK;
+  }
+  // delivered clouds: chunk c+1 is scattered and assembled while chunk c crosses PCIe
+  Chunk prev{0, 0, -1};
+  int prev_set = 0;
+  uint32_t e0 = 0;
+  int seq = 0;
+  auto complete = [&](const Chunk& c, int set) -> int32_t {
+    AsmSet& as = ctx->aset[set];
+    HIP_TRY(ctx, hipEventSynchronize(as.ready));
+    ChunkResult r;
+    int64_t min_rows = 0, min_segs = 0;
+    read_scatter(ctx, c.slot, c.n, &r, &min_rows, &min_segs);
+    for (int attempt = 0; r.overflow && attempt < 8; ++attempt) {
+      int32_t rc2;
+      if ((rc2 = enqueue_scatter(ctx, c.slot, lay, trk, seed, batch_first_global + c.e0, c.e0, c.n, min_rows, min_segs))) return rc2;
+      if ((rc2 = enqueue_assembly(ctx, c.slot, as, c.n, spyral))) return rc2;
+      HIP_TRY(ctx, hipEventSynchronize(as.ready));
+      read_scatter(ctx, c.slot, c.n, &r, &min_rows, &min_segs);
+    }
+    if (r.overflow) return fail(ctx, ATTPC_E_HIP, "point cloud did not fit after repeated buffer growth");
+    accumulate(st, r);
+    return deliver_chunk(ctx, as, c.n, batch_first_local + c.e0, spyral, out, row_cursor, over);
+  };
+  while (e0 < nb) {
+    const bool pilot = ctx->rows_per_event <= 0.0;  // only ever true with nothing in flight
+    const uint32_t n = next_chunk_events(ctx, nb - e0);
+    const Chunk c{e0, n, seq % MAX_SLOTS};
+    const int set = seq & 1;
+    // an overflow of the chunk in flight is repaired inside complete(); queue this one behind it
+    if ((rc = enqueue_scatter(ctx, c.slot, lay, trk, seed, batch_first_global + e0, e0, n, 0, 0))) return rc;
+    if ((rc = enqueue_assembly(ctx, c.slot, ctx->aset[set], n, spyral))) return rc;
+    if ((rc = queue_next_once())) return rc;
+    if (prev.slot >= 0 && (rc = complete(prev, prev_set))) return rc;
+    prev = c;
+    prev_set = set;
+    e0 += n;
+    seq++;
+    if (pilot) {  // size the following chunks from the pilot
+      if ((rc = complete(prev, prev_set))) return rc;
+      prev.slot = -1;
+    }
+  }
+  if (prev.slot >= 0 && (rc = complete(prev, prev_set))) return rc;
+  return queue_next_once();
+}
+
+int32_t run_events(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events, const attpc_event_layout& lay,
+                   const RunSource& src, const RunSink& sink, attpc_cloud_out* out, bool spyral, attpc_run_stats* stats) {
+  int32_t rc;
+  attpc_run_stats st{};
+  st.n_events = n_events;
+  const int n_rows = lay.n_rows;
+  int64_t row_cursor = 0;
+  bool over = false;
+  if (out && out->offsets) out->offsets[0] = 0;
+  // the first batch is one chunk (its tracks cannot hide behind a scatter), the following ones up to
+  // MAX_SLOTS chunks, each integrated on T while the previous batch is scattered on S
+  uint64_t b0 = 0;
+  int cur = 0;
+  TrackLaunch tl[2];
+  auto batch_size = [&](uint64_t at) -> uint32_t {
+    const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events);
+    uint64_t want = track_batch_events(ctx, lay, chunk);
+    if (at == 0) want = std::min<uint64_t>(want, ctx->blocks_per_track > 0.0 ? chunk : std::min<uint64_t>(chunk, 16384));
+    return (uint32_t)std::min<uint64_t>(want, n_events - at);
+  };
+  uint32_t nb = n_events ? batch_size(0) : 0;
+  if (nb && (rc = queue_batch(ctx, ctx->tset[cur], tl[cur], lay, src, seed, first_event, 0, nb, n_rows))) return rc;
+  while (nb) {
+    TrackSet& ts = ctx->tset[cur];
+    TrackBuffers trk;
+    if ((rc = finish_tracks(ctx, ts, tl[cur], &trk, &st.ms_tracks, &st.n_sample_limit))) return rc;
+    st.launches_tracks += 1;
+    if (ts.timed_kin) {
+      float ms_k = 0;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms_k, ts.k0, ts.k1));
+      st.ms_kinematics += ms_k;
+      st.launches_kinematics += 1;
+    }
+    // the next batch goes to the other set: the scatter chunks of the batch before this one have all
+    // been read, so that set is free
+    const uint64_t next_b0 = b0 + nb;
+    uint32_t next_nb = 0;
+    auto queue_next = [&]() -> int32_t {
+      if (next_b0 >= n_events) return ATTPC_OK;
+      next_nb = batch_size(next_b0);
+      return queue_batch(ctx, ctx->tset[cur ^ 1], tl[cur ^ 1], lay, src, seed, first_event, next_b0, next_nb, n_rows);
+    };
+    if (sink.status) HIP_TRY(ctx, hipMemcpyAsync(sink.status + b0, ts.status.p, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (sink.p4) HIP_TRY(ctx, hipMemcpyAsync(sink.p4 + b0 * n_rows * 4, ts.p4.p, (size_t)nb * n_rows * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (sink.vertex) HIP_TRY(ctx, hipMemcpyAsync(sink.vertex + b0 * 3, ts.vertex.p, (size_t)nb * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = run_batch_chunks(ctx, lay, trk, seed, first_event + b0, b0, nb, out, spyral, &st, &row_cursor, &over, queue_next))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // this set's readers are done before it is refilled
+    b0 = next_b0;
+    nb = next_nb;
+    cur ^= 1;
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
+  if (spyral) st.n_points = (uint64_t)row_cursor;  // rows that survive the threshold
+  if (stats) *stats = st;
+  if (over) return fail(ctx, ATTPC_E_CAPACITY, "cloud needs %lld rows, capacity %lld", (long long)row_cursor, (long long)out->capacity);
+  if (st.n_failed || st.n_inconsistent)
+    return fail(ctx, ATTPC_E_DATALOSS, "%llu events lost a time bucket (n_failed), %u table self-check failures (n_inconsistent) in %llu events",
+                (unsigned long long)st.n_failed, st.n_inconsistent, (unsigned long long)n_events);
   return ATTPC_OK;
 }
 
@@ -446,15 +824,28 @@ int32_t attpc_ctx_create(int32_t device, attpc_ctx** out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
   }
-  if (hipStreamCreate(&ctx->stream) != hipSuccess) {
-    delete ctx;
+  bool ok = true;
+  int prio_low = 0, prio_high = 0;
+  if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_low = prio_high = 0;
+  ok = ok && hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_high) == hipSuccess;
+  ok = ok && hipStreamCreateWithPriority(&ctx->stream_t, hipStreamNonBlocking, prio_low) == hipSuccess;
+  ok = ok && hipStreamCreateWithPriority(&ctx->stream_c, hipStreamNonBlocking, prio_high) == hipSuccess;
+  auto make_event = [&](hipEvent_t* e) { ok = ok && hipEventCreate(e) == hipSuccess; };
+  for (TrackSet& ts : ctx->tset) {
+    make_event(&ts.done); make_event(&ts.k0); make_event(&ts.k1); make_event(&ts.t0); make_event(&ts.t1);
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&ts.h_ctrl), 16 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  }
+  for (int i = 0; i < MAX_SLOTS; ++i) { make_event(&ctx->s0[i]); make_event(&ctx->s1[i]); }
+  for (AsmSet& as : ctx->aset) {
+    make_event(&as.ready); make_event(&as.copied);
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&as.h_total), 2 * sizeof(int64_t), hipHostMallocDefault) == hipSuccess;
+  }
+  ok = ok && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_out_ctrl), (size_t)MAX_SLOTS * CTRL_WORDS * sizeof(unsigned long long),
+                           hipHostMallocDefault) == hipSuccess;
+  if (!ok) {
+    attpc_ctx_destroy(ctx);
     return ATTPC_E_HIP;
   }
-  for (auto& e : ctx->ev)
-    if (hipEventCreate(&e) != hipSuccess) {
-      delete ctx;
-      return ATTPC_E_HIP;
-    }
   *out = ctx;
   return ATTPC_OK;
 }
@@ -462,21 +853,42 @@ int32_t attpc_ctx_create(int32_t device, attpc_ctx** out) {
 int32_t attpc_ctx_destroy(attpc_ctx* ctx) {
   if (!ctx) return ATTPC_OK;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream_t) (void)hipStreamSynchronize(ctx->stream_t);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream_c) (void)hipStreamSynchronize(ctx->stream_c);
   free_all(ctx->kin_allocs);
   free_all(ctx->det_allocs);
   free_all(ctx->spyral_allocs);
-  DevBuf* bufs[] = {&ctx->p4, &ctx->vertex, &ctx->status, &ctx->attempts, &ctx->arena, &ctx->block_table,
-                    &ctx->counts, &ctx->n_steps, &ctx->trk_ctrl, &ctx->points, &ctx->labels, &ctx->segments,
-                    &ctx->out_ctrl, &ctx->asm_labels, &ctx->sp_rows, &ctx->sp_labels,
-                    &ctx->sp_event_start, &ctx->sp_kept, &ctx->sp_kept_start};
+  std::vector<DevBuf*> bufs = {&ctx->points, &ctx->labels, &ctx->segments, &ctx->ev_rows, &ctx->lone_list, &ctx->out_ctrl,
+                               &ctx->sort_idx, &ctx->sort_key};
+  for (TrackSet& ts : ctx->tset) {
+    for (DevBuf* b : {&ts.p4, &ts.vertex, &ts.status, &ts.attempts, &ts.arena, &ts.block_table, &ts.counts, &ts.n_steps, &ts.ctrl})
+      bufs.push_back(b);
+    for (hipEvent_t e : {ts.done, ts.k0, ts.k1, ts.t0, ts.t1})
+      if (e) (void)hipEventDestroy(e);
+    if (ts.h_ctrl) (void)hipHostFree(ts.h_ctrl);
+  }
+  for (AsmSet& as : ctx->aset) {
+    for (DevBuf* b : {&as.ev_start, &as.points, &as.labels, &as.kept, &as.kept_start, &as.sp_rows, &as.sp_labels}) bufs.push_back(b);
+    for (hipEvent_t e : {as.ready, as.copied})
+      if (e) (void)hipEventDestroy(e);
+    if (as.h_start) (void)hipHostFree(as.h_start);
+    if (as.h_ev_rows) (void)hipHostFree(as.h_ev_rows);
+    if (as.h_total) (void)hipHostFree(as.h_total);
+  }
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& b : ctx->scratch)
     if (b.p) (void)hipFree(b.p);
-  for (auto& e : ctx->ev)
-    if (e) (void)hipEventDestroy(e);
+  for (int i = 0; i < MAX_SLOTS; ++i) {
+    if (ctx->s0[i]) (void)hipEventDestroy(ctx->s0[i]);
+    if (ctx->s1[i]) (void)hipEventDestroy(ctx->s1[i]);
+  }
+  if (ctx->h_out_ctrl) (void)hipHostFree(ctx->h_out_ctrl);
+  for (void* p : ctx->host_allocs) (void)hipHostFree(p);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream_t) (void)hipStreamDestroy(ctx->stream_t);
+  if (ctx->stream_c) (void)hipStreamDestroy(ctx->stream_c);
   delete ctx;
   return ATTPC_OK;
 }
@@ -489,11 +901,49 @@ int32_t attpc_set_chunk_events(attpc_ctx* ctx, int32_t chunk_events) {
   return ATTPC_OK;
 }
 
+int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value) {
+  if (!ctx || !name) return ATTPC_E_INVALID;
+  const std::string key(name);
+  if (key == "scatter_variant") {
+    if (value < 0 || value > 2) return fail(ctx, ATTPC_E_INVALID, "scatter_variant must be 0, 1 or 2");
+    ctx->opt_variant = (int)value;
+  } else if (key == "tiny_buffers") {
+    ctx->opt_tiny = value != 0;
+  } else if (key == "chunk_events") {
+    return attpc_set_chunk_events(ctx, (int32_t)value);
+  } else {
+    return fail(ctx, ATTPC_E_INVALID, "unknown option '%s'", name);
+  }
+  return ATTPC_OK;
+}
+
+int32_t attpc_host_alloc(attpc_ctx* ctx, uint64_t bytes, void** out) {
+  if (!ctx || !out) return ATTPC_E_INVALID;
+  *out = nullptr;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  void* p = nullptr;
+  HIP_TRY(ctx, hipHostMalloc(&p, std::max<uint64_t>(bytes, 1), hipHostMallocDefault));
+  ctx->host_allocs.push_back(p);
+  *out = p;
+  return ATTPC_OK;
+}
+
+int32_t attpc_host_free(attpc_ctx* ctx, void* ptr) {
+  if (!ctx) return ATTPC_E_INVALID;
+  if (!ptr) return ATTPC_OK;
+  auto it = std::find(ctx->host_allocs.begin(), ctx->host_allocs.end(), ptr);
+  if (it == ctx->host_allocs.end()) return fail(ctx, ATTPC_E_INVALID, "attpc_host_free: not an attpc_host_alloc pointer of this context");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
+  HIP_TRY(ctx, hipHostFree(ptr));
+  ctx->host_allocs.erase(it);
+  return ATTPC_OK;
+}
+
 int32_t attpc_sync(attpc_ctx* ctx) {
   if (!ctx) return ATTPC_E_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return ATTPC_OK;
+  return sync_all(ctx);
 }
 
 int32_t attpc_kin_configure(attpc_ctx* ctx, const attpc_kin_desc* d) {
@@ -501,9 +951,10 @@ int32_t attpc_kin_configure(attpc_ctx* ctx, const attpc_kin_desc* d) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (d->n_steps < 1 || d->n_steps > ATTPC_MAX_STEPS) return fail(ctx, ATTPC_E_INVALID, "n_steps=%d", d->n_steps);
   if (d->sample_limit < 1) return fail(ctx, ATTPC_E_INVALID, "sample_limit=%d", d->sample_limit);
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  { int32_t rc0 = sync_all(ctx); if (rc0) return rc0; }
   free_all(ctx->kin_allocs);
   ctx->kin_ready = false;
+  ctx->rows_per_event = ctx->segs_per_event = ctx->blocks_per_track = 0.0;  // another workload: size estimates start over
   attpc_kin_desc k = *d;
   int32_t rc;
   for (int s = 0; s < d->n_steps; ++s) {
@@ -549,16 +1000,17 @@ int32_t attpc_kin_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint6
   const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events) * 4;
   for (uint64_t done = 0; done < n_events; done += chunk) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(chunk, n_events - done);
-    int32_t rc = ensure_kin_buffers(ctx, n, n_rows);
+    TrackSet& ts = ctx->tset[0];
+    int32_t rc = ensure_kin_buffers(ctx, ts, n, n_rows);
     if (rc) return rc;
-    launch_kin_run(ctx->stream, ctx->kin, seed, first_event + done, n, static_cast<double*>(ctx->p4.p),
-                   static_cast<double*>(ctx->vertex.p), static_cast<int32_t*>(ctx->status.p),
-                   static_cast<uint32_t*>(ctx->attempts.p));
+    launch_kin_run(ctx->stream, ctx->kin, seed, first_event + done, n, static_cast<double*>(ts.p4.p),
+                   static_cast<double*>(ts.vertex.p), static_cast<int32_t*>(ts.status.p),
+                   static_cast<uint32_t*>(ts.attempts.p));
     HIP_TRY(ctx, hipGetLastError());
-    if (p4) HIP_TRY(ctx, hipMemcpyAsync(p4 + done * n_rows * 4, ctx->p4.p, (size_t)n * n_rows * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (vertex) HIP_TRY(ctx, hipMemcpyAsync(vertex + done * 3, ctx->vertex.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (status) HIP_TRY(ctx, hipMemcpyAsync(status + done, ctx->status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (attempts) HIP_TRY(ctx, hipMemcpyAsync(attempts + done, ctx->attempts.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (p4) HIP_TRY(ctx, hipMemcpyAsync(p4 + done * n_rows * 4, ts.p4.p, (size_t)n * n_rows * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (vertex) HIP_TRY(ctx, hipMemcpyAsync(vertex + done * 3, ts.vertex.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (status) HIP_TRY(ctx, hipMemcpyAsync(status + done, ts.status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (attempts) HIP_TRY(ctx, hipMemcpyAsync(attempts + done, ts.attempts.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   return ATTPC_OK;
@@ -629,9 +1081,18 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
   if (d->lut_n > 32000) return fail(ctx, ATTPC_E_INVALID, "pad look-up table larger than 32000 x 32000 (indices are staged as 16 bit)");
   if (d->windows_edge <= d->micromegas_edge) return fail(ctx, ATTPC_E_INVALID, "windows_edge <= micromegas_edge");
   if (!(d->length > 0.0) || !(d->w_value > 0.0)) return fail(ctx, ATTPC_E_INVALID, "length and w_value must be > 0");
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  {  // the scatter key packs the pad into 14 bits (tb << 14 | pad): ids outside [-1, 16383] would corrupt the
+     // time bucket bits; the reference only treats -1 as "no pad" (transporter.py:162,237)
+    const size_t cells = (size_t)d->lut_n * (size_t)d->lut_n;
+    for (size_t i = 0; i < cells; ++i)
+      if (d->pad_lut[i] < -1 || d->pad_lut[i] >= LONE_PADS)
+        return fail(ctx, ATTPC_E_INVALID, "pad look-up table holds pad id %d at cell %zu: ids must be in [-1, %d]", (int)d->pad_lut[i], i, LONE_PADS - 1);
+  }
+  { int32_t rc0 = sync_all(ctx); if (rc0) return rc0; }
   free_all(ctx->det_allocs);
   ctx->det_ready = false;
+  ctx->rows_per_event = ctx->segs_per_event = ctx->blocks_per_track = 0.0;  // size estimates start over
+  ctx->prefer_big = false;
   DetDev dv{};
   dv.length = d->length; dv.efield = d->efield; dv.bfield = d->bfield; dv.density = d->density;
   dv.diffusion = d->diffusion; dv.fano_factor = d->fano_factor; dv.w_value = d->w_value;
@@ -645,6 +1106,8 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
   for (int s = 0; s < ATTPC_LONG_STEPS; ++s) dv.long_weights[s] = d->long_weights[s];
   dv.mc_diffusion = d->mc_diffusion != 0 ? 1 : 0;
   dv.mpgd_gain32 = (int32_t)d->mpgd_gain;
+  if (!(d->path_step >= 0.0) || !(d->path_step < 1.0e300)) return fail(ctx, ATTPC_E_INVALID, "path_step must be >= 0 and finite");
+  dv.path_step = d->path_step;
   if (dv.mc_diffusion && (d->mpgd_gain < 1 || d->mpgd_gain > 0x7fffffff)) return fail(ctx, ATTPC_E_INVALID, "mc_diffusion needs 1 <= mpgd_gain < 2^31");
   int32_t rc;
   {  // device copy: [x][y] as given, padded with one extra row and column of -1 (index lut_n = "off
@@ -671,17 +1134,6 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
   return ATTPC_OK;
 }
 
-static void accumulate(attpc_run_stats* st, const ChunkResult& r) {
-  st->n_points += r.rows;
-  st->n_track_samples += r.samples;
-  st->n_failed += r.failed;
-  st->n_lds_overflow += r.retried;
-  st->charge_checksum += r.charge;
-  st->key_checksum += r.keys;
-  st->ms_scatter += r.ms_scatter;
-  st->launches_scatter += 1;
-  st->n_inconsistent += (uint32_t)r.mismatch;
-}
 
 int32_t attpc_det_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
                       const attpc_event_layout* layout, const double* p4, const double* vertex,
@@ -689,35 +1141,12 @@ int32_t attpc_det_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint6
   if (!ctx || !p4 || !vertex) return ATTPC_E_INVALID;
   if (!ctx->det_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_det_configure has not been called");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int32_t rc = validate_layout(ctx, layout);
+  int32_t rc = validate_layout(ctx, layout, true);
   if (rc) return rc;
-  attpc_run_stats st{};
-  st.n_events = n_events;
-  const int n_rows = layout->n_rows;
-  const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events);
-  const uint64_t batch = track_batch_events(ctx, *layout);
-  int64_t row_cursor = 0;
-  bool over = false;
-  if (out && out->offsets) out->offsets[0] = 0;
-  for (uint64_t b0 = 0; b0 < n_events; b0 += batch) {
-    const uint32_t nb = (uint32_t)std::min<uint64_t>(batch, n_events - b0);
-    if ((rc = ensure_kin_buffers(ctx, nb, n_rows))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->p4.p, p4 + b0 * n_rows * 4, (size_t)nb * n_rows * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->vertex.p, vertex + b0 * 3, (size_t)nb * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    TrackBuffers trk;
-    if ((rc = run_tracks(ctx, *layout, seed, first_event + b0, nb, false, &trk, &st.ms_tracks))) return rc;
-    st.launches_tracks += 1;
-    for (uint32_t e0 = 0; e0 < nb; e0 += (uint32_t)chunk) {
-      const uint32_t n = (uint32_t)std::min<uint64_t>(chunk, nb - e0);
-      ChunkResult r;
-      if ((rc = run_scatter(ctx, *layout, trk, seed, first_event + b0 + e0, e0, n, &r))) return rc;
-      accumulate(&st, r);
-      if (out && (rc = assemble_chunk(ctx, r, n, b0 + e0, out, &row_cursor, &over))) return rc;
-    }
-  }
-  if (stats) *stats = st;
-  if (over) return fail(ctx, ATTPC_E_CAPACITY, "cloud needs %lld rows, capacity %lld", (long long)row_cursor, (long long)out->capacity);
-  return ATTPC_OK;
+  RunSource src;
+  src.h_p4 = p4;
+  src.h_vertex = vertex;
+  return run_events(ctx, seed, first_event, n_events, *layout, src, RunSink{}, out, false, stats);
 }
 
 static int32_t sim_run_impl(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
@@ -728,56 +1157,17 @@ static int32_t sim_run_impl(attpc_ctx* ctx, uint64_t seed, uint64_t first_event,
   if (!ctx->kin_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_kin_configure has not been called");
   if (!ctx->det_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_det_configure has not been called");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int32_t rc = validate_layout(ctx, layout);
+  int32_t rc = validate_layout(ctx, layout, true);
   if (rc) return rc;
   const int n_rows = 4 + 2 * (ctx->kin.n_steps - 1);
   if (layout->n_rows != n_rows) return fail(ctx, ATTPC_E_INVALID, "layout.n_rows=%d but the pipeline has %d rows", layout->n_rows, n_rows);
-  attpc_run_stats st{};
-  st.n_events = n_events;
-  const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events);
-  const uint64_t batch = track_batch_events(ctx, *layout);
-  int64_t row_cursor = 0;
-  bool over = false;
-  if (out && out->offsets) out->offsets[0] = 0;
-  std::vector<int32_t> hstatus;
-  for (uint64_t b0 = 0; b0 < n_events; b0 += batch) {
-    const uint32_t nb = (uint32_t)std::min<uint64_t>(batch, n_events - b0);
-    if ((rc = ensure_kin_buffers(ctx, nb, n_rows))) return rc;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    launch_kin_run(ctx->stream, ctx->kin, seed, first_event + b0, nb, static_cast<double*>(ctx->p4.p),
-                   static_cast<double*>(ctx->vertex.p), static_cast<int32_t*>(ctx->status.p),
-                   static_cast<uint32_t*>(ctx->attempts.p));
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-    TrackBuffers trk;
-    if ((rc = run_tracks(ctx, *layout, seed, first_event + b0, nb, true, &trk, &st.ms_tracks))) return rc;
-    float ms_k = 0;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms_k, ctx->ev[4], ctx->ev[5]));
-    st.ms_kinematics += ms_k;
-    st.launches_kinematics += 1;
-    st.launches_tracks += 1;
-    hstatus.resize(nb);
-    HIP_TRY(ctx, hipMemcpy(hstatus.data(), ctx->status.p, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (int32_t s : hstatus) st.n_sample_limit += (s != 0);
-    if (kin_status) std::memcpy(kin_status + b0, hstatus.data(), (size_t)nb * sizeof(int32_t));
-    if (p4) HIP_TRY(ctx, hipMemcpy(p4 + b0 * n_rows * 4, ctx->p4.p, (size_t)nb * n_rows * 4 * sizeof(double), hipMemcpyDeviceToHost));
-    if (vertex) HIP_TRY(ctx, hipMemcpy(vertex + b0 * 3, ctx->vertex.p, (size_t)nb * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    for (uint32_t e0 = 0; e0 < nb; e0 += (uint32_t)chunk) {
-      const uint32_t n = (uint32_t)std::min<uint64_t>(chunk, nb - e0);
-      ChunkResult r;
-      if ((rc = run_scatter(ctx, *layout, trk, seed, first_event + b0 + e0, e0, n, &r))) return rc;
-      accumulate(&st, r);
-      if (out) {
-        rc = spyral ? assemble_chunk_spyral(ctx, r, n, b0 + e0, out, &row_cursor, &over)
-                    : assemble_chunk(ctx, r, n, b0 + e0, out, &row_cursor, &over);
-        if (rc) return rc;
-      }
-    }
-  }
-  if (spyral) st.n_points = (uint64_t)row_cursor;  // rows that survive the threshold
-  if (stats) *stats = st;
-  if (over) return fail(ctx, ATTPC_E_CAPACITY, "cloud needs %lld rows, capacity %lld", (long long)row_cursor, (long long)out->capacity);
-  return ATTPC_OK;
+  RunSource src;
+  src.from_kernel = true;
+  RunSink sink;
+  sink.p4 = p4;
+  sink.vertex = vertex;
+  sink.status = kin_status;
+  return run_events(ctx, seed, first_event, n_events, *layout, src, sink, out, spyral, stats);
 }
 
 int32_t attpc_sim_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
@@ -797,7 +1187,7 @@ int32_t attpc_spyral_configure(attpc_ctx* ctx, const attpc_spyral_desc* d) {
   if (!ctx || !d || !d->response || !d->pad_centers || !d->pad_sizes || d->n_pads < 1) return ATTPC_E_INVALID;
   if (d->windows_edge <= d->micromegas_edge) return fail(ctx, ATTPC_E_INVALID, "windows_edge <= micromegas_edge");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  { int32_t rc0 = sync_all(ctx); if (rc0) return rc0; }
   free_all(ctx->spyral_allocs);
   ctx->spyral_ready = false;
   SpyralDev sp{};
@@ -829,28 +1219,29 @@ int32_t attpc_det_tracks(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, ui
   if (!ctx || !p4 || !vertex || !counts || !n_steps) return ATTPC_E_INVALID;
   if (!ctx->det_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_det_configure has not been called");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int32_t rc = validate_layout(ctx, layout);
+  int32_t rc = validate_layout(ctx, layout, true);
   if (rc) return rc;
   if (n_events > (uint64_t)ctx->chunk_events) return fail(ctx, ATTPC_E_INVALID, "attpc_det_tracks handles at most one chunk");
   const uint32_t n = (uint32_t)n_events;
-  const int n_rows = layout->n_rows;
-  if ((rc = ensure_kin_buffers(ctx, n, n_rows))) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->p4.p, p4, (size_t)n * n_rows * 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->vertex.p, vertex, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  TrackSet& ts = ctx->tset[0];
+  TrackLaunch tl;
+  RunSource src;
+  src.h_p4 = p4;
+  src.h_vertex = vertex;
+  if ((rc = queue_batch(ctx, ts, tl, *layout, src, seed, first_event, 0, n, layout->n_rows))) return rc;
   TrackBuffers trk;
   double ms = 0;
-  if ((rc = run_tracks(ctx, *layout, seed, first_event, n, false, &trk, &ms))) return rc;
+  if ((rc = finish_tracks(ctx, ts, tl, &trk, &ms, nullptr))) return rc;
   const uint32_t n_tracks = n * (uint32_t)layout->n_sim;
-  uint32_t tctrl[4];
-  HIP_TRY(ctx, hipMemcpy(tctrl, ctx->trk_ctrl.p, sizeof tctrl, hipMemcpyDeviceToHost));
+  if (n_tracks == 0) return ATTPC_OK;
   std::vector<int32_t> table((size_t)n_tracks * MAX_BLOCKS_PER_TRACK);
-  HIP_TRY(ctx, hipMemcpy(table.data(), ctx->block_table.p, table.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(counts, ctx->counts.p, (size_t)n_tracks * sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(n_steps, ctx->n_steps.p, (size_t)n_tracks * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(table.data(), ts.block_table.p, table.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(counts, ts.counts.p, (size_t)n_tracks * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(n_steps, ts.n_steps.p, (size_t)n_tracks * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (samples) {
-    // tctrl[1] counts reserved blocks (waves reserve pools), all below arena_blocks after a good run
-    std::vector<double> arena(std::min<size_t>(tctrl[1], ctx->arena_blocks) * ARENA_BLK * 4);
-    if (!arena.empty()) HIP_TRY(ctx, hipMemcpy(arena.data(), ctx->arena.p, arena.size() * sizeof(double), hipMemcpyDeviceToHost));
+    // h_ctrl[1] counts reserved blocks (waves reserve pools), all below arena_blocks after a good run
+    std::vector<double> arena(std::min<size_t>(ts.h_ctrl[1], ts.arena_blocks) * ARENA_BLK * 4);
+    if (!arena.empty()) HIP_TRY(ctx, hipMemcpy(arena.data(), ts.arena.p, arena.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (uint32_t t = 0; t < n_tracks; ++t) {
       const int64_t c = std::min<int64_t>(counts[t], max_samples_per_track);
       for (int64_t s = 0; s < c; ++s) {
@@ -860,6 +1251,72 @@ int32_t attpc_det_tracks(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, ui
       }
     }
   }
+  return ATTPC_OK;
+}
+
+int32_t attpc_det_scatter(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                          const attpc_event_layout* layout, const double* samples, const int32_t* counts,
+                          attpc_cloud_out* out, attpc_run_stats* stats) {
+  if (!ctx || !counts || !layout) return ATTPC_E_INVALID;
+  if (!ctx->det_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_det_configure has not been called");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int32_t rc = validate_layout(ctx, layout, false);
+  if (rc) return rc;
+  if (n_events > (uint64_t)ctx->chunk_events) return fail(ctx, ATTPC_E_INVALID, "attpc_det_scatter handles at most one chunk");
+  const uint32_t n = (uint32_t)n_events;
+  const uint32_t n_tracks = n * (uint32_t)layout->n_sim;
+  // pack the samples into arena blocks, one chain of consecutive blocks per track
+  std::vector<int32_t> table((size_t)n_tracks * MAX_BLOCKS_PER_TRACK, 0);
+  size_t total_samples = 0, n_blocks = 0;
+  for (uint32_t t = 0; t < n_tracks; ++t) {
+    if (counts[t] < 0 || counts[t] > MAX_BLOCKS_PER_TRACK * ARENA_BLK)
+      return fail(ctx, ATTPC_E_INVALID, "counts[%u]=%d: a track holds 0..%d samples", t, counts[t], MAX_BLOCKS_PER_TRACK * ARENA_BLK);
+    total_samples += (size_t)counts[t];
+    n_blocks += ((size_t)counts[t] + ARENA_BLK - 1) / ARENA_BLK;
+  }
+  if (total_samples && !samples) return ATTPC_E_INVALID;
+  std::vector<double> arena(std::max<size_t>(n_blocks, 1) * ARENA_BLK * 4, 0.0);
+  size_t blk = 0, src_row = 0;
+  for (uint32_t t = 0; t < n_tracks; ++t) {
+    const size_t nb = ((size_t)counts[t] + ARENA_BLK - 1) / ARENA_BLK;
+    for (size_t b = 0; b < nb; ++b) table[(size_t)t * MAX_BLOCKS_PER_TRACK + b] = (int32_t)(blk + b);
+    if (counts[t]) std::memcpy(arena.data() + blk * ARENA_BLK * 4, samples + src_row * 4, (size_t)counts[t] * 4 * sizeof(double));
+    blk += nb;
+    src_row += (size_t)counts[t];
+  }
+  if ((rc = sync_all(ctx))) return rc;
+  TrackSet& ts = ctx->tset[0];
+  if ((rc = ensure(ctx, ts.arena, arena.size() * sizeof(double)))) return rc;
+  ts.arena_blocks = std::max(ts.arena_blocks, arena.size() / ((size_t)ARENA_BLK * 4));
+  if ((rc = ensure(ctx, ts.block_table, std::max<size_t>(table.size(), 1) * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(ctx, ts.counts, std::max<size_t>(n_tracks, 1) * sizeof(int32_t)))) return rc;
+  HIP_TRY(ctx, hipMemcpy(ts.arena.p, arena.data(), arena.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (n_tracks) {
+    HIP_TRY(ctx, hipMemcpy(ts.block_table.p, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ts.counts.p, counts, (size_t)n_tracks * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  TrackBuffers trk{};
+  trk.arena = static_cast<double*>(ts.arena.p);
+  trk.block_table = static_cast<int32_t*>(ts.block_table.p);
+  trk.counts = static_cast<int32_t*>(ts.counts.p);
+  trk.arena_blocks = (uint32_t)ts.arena_blocks;
+  attpc_run_stats st{};
+  st.n_events = n_events;
+  int64_t row_cursor = 0;
+  bool over = false;
+  if (out && out->offsets) out->offsets[0] = 0;
+  const double keep_rows = ctx->rows_per_event, keep_segs = ctx->segs_per_event;
+  ctx->rows_per_event = ctx->segs_per_event = 0.0;  // explicit samples say nothing about the configured workload
+  rc = run_batch_chunks(ctx, *layout, trk, seed, first_event, 0, n, out, false, &st, &row_cursor, &over, []() -> int32_t { return ATTPC_OK; });
+  ctx->rows_per_event = keep_rows;
+  ctx->segs_per_event = keep_segs;
+  if (rc) return rc;
+  if ((rc = sync_all(ctx))) return rc;
+  if (stats) *stats = st;
+  if (over) return fail(ctx, ATTPC_E_CAPACITY, "cloud needs %lld rows, capacity %lld", (long long)row_cursor, (long long)out->capacity);
+  if (st.n_failed || st.n_inconsistent)
+    return fail(ctx, ATTPC_E_DATALOSS, "%llu events lost a time bucket (n_failed), %u table self-check failures (n_inconsistent)",
+                (unsigned long long)st.n_failed, st.n_inconsistent);
   return ATTPC_OK;
 }
 

@@ -100,7 +100,9 @@ __device__ __forceinline__ double dedx_lookup(TablePtr tab, double ke) {
 // read the OLD index and worked on another event than wave 0).  Never seen with one workgroup per CU;
 // about once per 20 000 windows when two workgroups share a CU and contend for the LDS.
 __device__ __forceinline__ void block_sync() {
+#ifndef ATTPC_BARE_BARRIER  // (defined only by tests/test_isa_barriers.py to show what the checker catches)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
   __syncthreads();
 }
 
@@ -122,6 +124,7 @@ struct DetDev {
   double long_weights[ATTPC_LONG_STEPS];
   int32_t mc_diffusion;                     // extension: per-electron Monte-Carlo transverse diffusion
   int32_t mpgd_gain32;
+  double path_step;                         // extension: track sample every path_step metres, 0 = time grid
 };
 
 // track sample arena: blocks of ARENA_BLK samples, each sample = (x, y, time bucket, electrons)
@@ -141,6 +144,17 @@ struct Segment {          // one flushed window of one event
   int32_t event;          // chunk-local event
   int32_t count;
   int64_t offset;         // row offset into the chunk's points/labels
+  int64_t ev_offset;      // rows of the same event flushed before this window (its place in the event's CSR range)
+};
+
+// A single time bucket of an event that holds more keys than the scatter kernel's LDS table is left out
+// there, recorded as a LoneBucket and scattered by lone_bucket_kernel (lone.hip) right behind it: inside
+// one bucket the key is the pad, so that kernel's table is direct mapped over the 14-bit pad range of the
+// key -- no hashing and no capacity limit (the reference's dict has none, simulator.py:93-101).
+constexpr int LONE_PADS = 1 << 14;
+struct LoneBucket {
+  uint32_t event;   // launch-local event
+  uint32_t tb;      // time bucket
 };
 
 struct CloudBuffers {
@@ -149,7 +163,10 @@ struct CloudBuffers {
   Segment* segments;
   unsigned long long* ctrl;  // [0] row cursor, [1] segment cursor, [2] charge sum, [3] key sum,
                              // [4] failed events, [5] overflow windows retried, [6] out-of-capacity flag,
-                             // [7] samples
+                             // [7] samples, [29] lone-bucket windows (global-memory table)
+  uint32_t* ev_rows;         // [n_events] cloud rows of every event of the launch
+  LoneBucket* lone_list;     // [lone_capacity] time buckets left to lone_bucket_kernel, count in ctrl[29]
+  uint32_t lone_capacity;
   int64_t capacity;
   int64_t seg_capacity;
 };

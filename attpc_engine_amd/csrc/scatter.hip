@@ -113,6 +113,7 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t KEY_MASK = 0x00FFFFFFu;
 constexpr int SEG_BLOCK = 16;        // segment slots reserved at a time
 constexpr int CTRL_NEXT_EVENT = 28;  // out.ctrl[]: next unassigned event of the launch
+constexpr int CTRL_LONE = 29;        // out.ctrl[]: time buckets left to lone_bucket_kernel (entries of out.lone_list)
 constexpr int CTRL_ROWS = 30;        // out.ctrl[]: rows actually written ([0] is the reservation cursor)
 constexpr int CTRL_MISMATCH = 31;    // out.ctrl[]: windows whose occupied-slot count differed from the claimed keys
 static_assert(STAGE <= SC_THREADS, "one lane per staged entry");
@@ -171,6 +172,7 @@ struct __align__(16) ScatterShared {
   unsigned long long base;
   unsigned long long row_cur, row_end, seg_cur, seg_end;  // this workgroup's reserved output rows / segment slots
   unsigned long long wg_samples, wg_rows;                 // workgroup totals (thread 0)
+  unsigned long long ev_rows;                             // rows of the current event flushed so far (thread 0)
   unsigned long long charge_sum, key_sum;
 };
 
@@ -418,6 +420,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
         const int zero = local_const(0);
         sh.win_a = zero; sh.win_b = zero; sh.budget = local_const(TARGET_KEYS); sh.overflow = zero; sh.done = zero;
         sh.ev_failed = zero;
+        sh.ev_rows = 0ull;
         sh.wg_samples += (unsigned long long)acc;
       }
       // the arena block ids of the event's tracks, loaded together with the counts (entries past a
@@ -815,14 +818,22 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
         if (sh.overflow) {
           block_sync();
           clear_table(sh);
-          if (tid < 64) {  // wave 0: same window start, smaller budget (a lone bucket is skipped)
-            const bool lone = win_b - win_a <= 1;  // one time bucket alone exceeds the table: not representable
+          if (tid < 64) {  // wave 0: same window start, smaller budget (a lone bucket is left to lone_bucket_kernel)
+            const bool lone = win_b - win_a <= 1;  // one time bucket alone exceeds the table
             const int budget = lone ? local_const(TARGET_KEYS) : (sh.win_samples / 2 > 0 ? sh.win_samples / 2 : 1);
             if (tid == 0) {
               sh.retried++;
               if (lone) {
-                if (!sh.ev_failed) sh.failed++;  // events with a time bucket that alone exceeds the table
-                sh.ev_failed = 1;
+                const unsigned long long slot = atomicAdd(&a.out.ctrl[CTRL_LONE], 1ull);
+                if (slot < (unsigned long long)a.out.lone_capacity) {
+                  LoneBucket lb;
+                  lb.event = e_local;
+                  lb.tb = (uint32_t)win_a;
+                  a.out.lone_list[slot] = lb;
+                } else {  // list full: the bucket is lost and the host raises (n_failed)
+                  if (!sh.ev_failed) sh.failed++;
+                  sh.ev_failed = 1;
+                }
               }
               sh.overflow = 0;
               sh.n_keys = 0u;
@@ -904,11 +915,13 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
               sg.event = (int32_t)e_local;
               sg.count = (int32_t)n_rows;
               sg.offset = (int64_t)base;
+              sg.ev_offset = (int64_t)sh.ev_rows;
               a.out.segments[g_seg] = sg;
             }
           }
           sh.base = base;
           sh.n_keys = 0u;
+          sh.ev_rows += n_rows;
           PHASE_MARK(17);  // segment written
         }
         if (tid < 64) {  // wave 0 chooses the next window; the barrier after the row stores publishes it
@@ -949,6 +962,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
         // staging overlap the store acknowledgements
         PHASE_MARK(7);
       }
+      if (tid == 0) a.out.ev_rows[e_local] = (uint32_t)sh.ev_rows;  // thread 0 is the only writer of sh.ev_rows
     }
     if (tid == 0) {  // events without any window never reached the request above
       sh.batch_first = have_next ? next_first : take_batch();
@@ -976,7 +990,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
     if (sh.retried) atomicAdd(&a.out.ctrl[5], (unsigned long long)sh.retried);
     // reserved but unused segment slots read as empty segments
     Segment none;
-    none.event = 0; none.count = 0; none.offset = 0;
+    none.event = 0; none.count = 0; none.offset = 0; none.ev_offset = 0;
     for (unsigned long long g = sh.seg_cur; g < sh.seg_end && g < (unsigned long long)a.out.seg_capacity; ++g)
       a.out.segments[g] = none;
   }

@@ -70,6 +70,9 @@ __device__ __forceinline__ void rhs(const double s[6], const Decomp& d, const Sp
   r[5] = sc.qm_e - dec * s[5];
 }
 
+// PATH: the path-length sampling extension (DetDev::path_step > 0) -- its own instantiation, so that
+// the reference time-grid kernel keeps its register budget (167 VGPRs = 3 waves per SIMD) and its code.
+template <bool PATH>
 __global__ __launch_bounds__(TRACK_THREADS) void track_kernel(TrackArgs a) {
   extern __shared__ double lds_tab[];  // [n_species][ATTPC_DEDX_NODES]
   const int n_tab = a.det.n_species * ATTPC_DEDX_NODES;
@@ -78,7 +81,9 @@ __global__ __launch_bounds__(TRACK_THREADS) void track_kernel(TrackArgs a) {
 
   const int lane = threadIdx.x & 63;
   const int nsub = a.det.ode_substeps > 0 ? a.det.ode_substeps : 1;
-  const double h = 1.0e-10 / (double)nsub;
+  const double h_grid = 1.0e-10 / (double)nsub;
+  double h = h_grid;      // PATH: per lane and per sample
+  double t_now = 0.0;     // PATH: time of the last recorded sample
   const double e_scale = 1.0e6 / a.det.w_value;
 
   bool active = false, retired = false;
@@ -165,6 +170,7 @@ __global__ __launch_bounds__(TRACK_THREADS) void track_kernel(TrackArgs a) {
             event = a.first_event + e_local;
             fano_domain = DOMAIN_FANO0 + (uint32_t)row;
             z_cache_idx = -1;
+            t_now = 0.0;
             active = true;
           }
         }
@@ -175,6 +181,23 @@ __global__ __launch_bounds__(TRACK_THREADS) void track_kernel(TrackArgs a) {
     for (int it = 0; it < STEPS_PER_REFILL; ++it) {
       bool stop = false;
       long long n_el = 0;
+      if constexpr (PATH) {
+        if (active) {
+          // sample every path_step of arc length, never coarser than the reference grid; the speed is
+          // that of the last recorded sample (include/attpc_engine.h, attpc_det_desc::path_step)
+          const double gv2 = s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
+          const double v = C_LIGHT * sqrt(gv2 / (1.0 + gv2));
+          double h_sample = a.det.path_step / v;
+          h_sample = h_sample < 1.0e-10 ? h_sample : 1.0e-10;
+          if (t_now + h_sample > 1.0e-6 * (1.0 + 1.0e-9)) {  // end of the recording window
+            a.buf.counts[tid] = count;
+            a.buf.n_steps[tid] = k + 1;
+            active = false;
+          }
+          t_now += h_sample;
+          h = h_sample / (double)nsub;
+        }
+      }
       if (active) {
         for (int sub = 0; sub < nsub && !stop; ++sub) {
           double k1[6], k2[6], k3[6], k4[6], y[6];
@@ -281,7 +304,10 @@ __global__ __launch_bounds__(TRACK_THREADS) void track_kernel(TrackArgs a) {
 }
 
 void launch_track_kernel(uint32_t blocks, size_t lds_bytes, hipStream_t s, const TrackArgs& a) {
-  hipLaunchKernelGGL(track_kernel, dim3(blocks), dim3(TRACK_THREADS), lds_bytes, s, a);
+  if (a.det.path_step > 0.0)
+    hipLaunchKernelGGL(track_kernel<true>, dim3(blocks), dim3(TRACK_THREADS), lds_bytes, s, a);
+  else
+    hipLaunchKernelGGL(track_kernel<false>, dim3(blocks), dim3(TRACK_THREADS), lds_bytes, s, a);
 }
 
 }  // namespace attpc

@@ -40,6 +40,8 @@ void launch_track_kernel(uint32_t blocks, size_t lds_bytes, hipStream_t s, const
 // scatter.hip compiled as it is / through scatter_small.hip (workgroups per CU: 1 / 2)
 void launch_scatter_kernel_big(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a);
 void launch_scatter_kernel_small(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a);
+// lone.hip: the time buckets scatter_kernel recorded in out.lone_list (normally none: exits at once)
+void launch_lone_bucket_kernel(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a);
 
 // response + threshold + Spyral rows on device (spyral.hip)
 struct SpyralDev {
@@ -53,9 +55,10 @@ struct SpyralDev {
   double window_edge, mm_edge, length, threshold;
 };
 void launch_spyral_count(hipStream_t s, const SpyralDev& sp, uint32_t n_events, const int64_t* event_start,
-                         const double* points, int32_t* kept);
+                         const double* points, uint32_t* kept);
+// rows of every event sorted by z (writer.py:236-238); sort_scratch: one u32 + one f64 per cloud row of the chunk
 void launch_spyral_write(hipStream_t s, const SpyralDev& sp, uint32_t n_events, const int64_t* event_start,
                          const int64_t* kept_start, const double* points, const int64_t* labels, double* rows,
-                         int64_t* out_labels);
+                         int64_t* out_labels, uint32_t* sort_idx, double* sort_key);
 
 }  // namespace attpc

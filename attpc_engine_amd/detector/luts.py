@@ -17,6 +17,9 @@ from .. import _abi
 from .beam_pads import BEAM_PADS_ARRAY
 
 
+MAX_PAD_ID = (1 << 14) - 1  # pad field of the scatter key (csrc/common.hpp LONE_PADS)
+
+
 def dedx_node_energies() -> np.ndarray:
     """Kinetic energies (MeV) of the ``DEDX_NODES`` table nodes."""
     e = np.arange(_abi.DEDX_EMIN, _abi.DEDX_EMAX)
@@ -51,7 +54,14 @@ def compact_pad_lut(pad_grid: np.ndarray, edges: np.ndarray) -> tuple[np.ndarray
     idx = ((ks - low) / step).astype(np.int64)
     if idx.size == 0 or idx.max() >= pad_grid.shape[0] or idx.max() >= pad_grid.shape[1]:
         raise ValueError("pad grid edges do not match the pad grid shape")
-    lut = np.ascontiguousarray(pad_grid[np.ix_(idx, idx)]).astype(np.int16)
+    cells = np.asarray(pad_grid[np.ix_(idx, idx)])
+    # the device key packs the pad into 14 bits (tb << 14 | pad) and the table is int16: ids outside
+    # [-1, 16383] would silently corrupt time buckets or wrap negative (the reference accepts any id
+    # and only treats -1 as "no pad", transporter.py:162,237)
+    if cells.size and (cells.min() < -1 or cells.max() >= MAX_PAD_ID + 1):
+        raise ValueError(f"pad grid holds pad ids in [{int(cells.min())}, {int(cells.max())}]: the engine needs "
+                         f"-1 (no pad) or 0..{MAX_PAD_ID}")
+    lut = np.ascontiguousarray(cells).astype(np.int16)
     return lut, k_min
 
 
@@ -103,6 +113,7 @@ def build_det_desc(config, nuclei: list, ode_substeps: int = 1, fold_beam: bool 
     for s, w in enumerate(longitudinal_weights()):
         desc.long_weights[s] = w
     desc.mc_diffusion = 1 if getattr(det, "mc_diffusion", False) else 0
+    desc.path_step = float(getattr(det, "path_step", 0.0) or 0.0)
     for i, nuc in enumerate(nuclei):
         table = sample_dedx_table(det.gas_target, nuc)
         keep.append(table)

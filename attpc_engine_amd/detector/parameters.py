@@ -29,7 +29,10 @@ class DetectorParams:
     ``longitudinal_diffusion`` [V] is an opt-in EXTENSION (the reference has no longitudinal
     diffusion, docs/user_guide/detector/index.md:130-133); 0 keeps the reference behaviour.
     ``mc_diffusion`` (EXTENSION) replaces the deterministic 10x10 mesh by one Gaussian step per
-    primary electron (seeded, reproducible); False keeps the reference behaviour."""
+    primary electron (seeded, reproducible); False keeps the reference behaviour.
+    ``path_step`` [m] (EXTENSION; the reference samples tracks on a fixed 1e-10 s grid, solver.py:16)
+    records a track sample / dE/dx step every ``path_step`` of arc length (never coarser than the
+    reference grid); 0 keeps the reference behaviour."""
 
     length: float
     efield: float
@@ -41,6 +44,7 @@ class DetectorParams:
     w_value: float
     longitudinal_diffusion: float = 0.0
     mc_diffusion: bool = False
+    path_step: float = 0.0
 
 
 @dataclass

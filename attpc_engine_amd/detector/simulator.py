@@ -37,7 +37,8 @@ def configure_detector(config: Config, species_keys: list[tuple[int, int]], ctx:
     dp = config.det_params
     token = (id(config), tuple(species_keys), ode_substeps, config.drift_velocity, dp.length, dp.efield,
              dp.bfield, dp.mpgd_gain, id(dp.gas_target), dp.diffusion, dp.fano_factor, dp.w_value,
-             getattr(dp, "longitudinal_diffusion", 0.0), getattr(dp, "mc_diffusion", False))
+             getattr(dp, "longitudinal_diffusion", 0.0), getattr(dp, "mc_diffusion", False),
+             getattr(dp, "path_step", 0.0))
     if getattr(ctx, "_det_token", None) == token:
         return
     nuclei = [_nuclear_map().get_data(z, a) for (z, a) in species_keys]

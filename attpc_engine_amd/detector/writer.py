@@ -2,9 +2,10 @@
 
 ``SimulationWriter`` is the protocol ``run_simulation`` drives (write once per non-empty
 event in event order, then close).  ``SpyralWriter`` produces the Spyral layout; the
-per-point response scaling / row conversion runs on the device (``attpc_spyral_rows``),
-thresholding and the z-sort stay in numpy.  h5py is imported lazily; without it the
-same datasets go to one ``.npz`` per run file.
+per-point response scaling / row conversion runs on the device (``attpc_spyral_rows``; the
+fused path ``Engine.run_spyral`` also thresholds and z-sorts there).  h5py is imported lazily;
+without it the same datasets go to one ``.npz`` per run file, after a warning (the HDF5 layout is
+"parity unpinned" in this container; tests drive it through a stand-in module).
 """
 from __future__ import annotations
 
@@ -96,8 +97,9 @@ class SpyralWriter:
     max_event on the group."""
 
     def __init__(self, directory_path: Path, config: Config, max_events_per_file: int = 5_000,
-                 first_run_number: int = 0):
+                 first_run_number: int = 0, npz_fallback: bool = True):
         self.directory_path = Path(directory_path)
+        self.npz_fallback = npz_fallback  # without h5py: warn and write .npz (True) or raise (False)
         self.response = get_response(config).copy()
         self.max_events_per_file = max_events_per_file
         self.run_number = first_run_number
@@ -107,13 +109,11 @@ class SpyralWriter:
         self.file = self._open(self.run_number)
 
     def _open(self, run_number: int):
-        path = self.directory_path / f"run_{run_number:04d}.h5"
-        try:
-            import h5py  # type: ignore
+        from ..io import hdf5_or_fallback
 
-            return _H5RunFile(path, h5py)
-        except ImportError:
-            return _NpzRunFile(path)
+        path = self.directory_path / f"run_{run_number:04d}.h5"
+        h5py = hdf5_or_fallback(path, self.npz_fallback)
+        return _H5RunFile(path, h5py) if h5py is not None else _NpzRunFile(path)
 
     def create_next_file(self) -> None:
         self.run_number += 1
@@ -130,16 +130,18 @@ class SpyralWriter:
         keep = rows[:, 3] > config.elec_params.adc_threshold  # writer.py:232-234
         self.write_rows(rows[keep], labels[keep], event_number)
 
-    def write_rows(self, rows: np.ndarray, labels: np.ndarray, event_number: int) -> None:
-        """Already converted and thresholded rows [P',8] (e.g. from ``Engine.run_spyral``): z-sort
-        (writer.py:236-238), file roll-over (:214-218), datasets and attributes (:240-251)."""
+    def write_rows(self, rows: np.ndarray, labels: np.ndarray, event_number: int, presorted: bool = False) -> None:
+        """Already converted and thresholded rows [P',8]: z-sort (writer.py:236-238) unless the rows
+        come ``presorted`` from the device (``Engine.run_spyral``), file roll-over (:214-218), datasets
+        and attributes (:240-251)."""
         if self.events_written == self.max_events_per_file:
             self.close()
             self.create_next_file()
             self.starting_event = event_number
             self.events_written = 0
-        order = np.argsort(rows[:, 2])
-        rows, labels = rows[order], labels[order]
+        if not presorted:
+            order = np.argsort(rows[:, 2])
+            rows, labels = rows[order], labels[order]
         self.file.create_dataset(
             f"cloud_{event_number}", rows,
             {"orig_run": self.run_number, "orig_event": event_number, "ic_amplitude": -1.0,

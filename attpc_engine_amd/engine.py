@@ -41,13 +41,30 @@ class Engine:
             ctx.check(ctx.lib.attpc_set_chunk_events(ctx.handle, int(chunk_events)), "attpc_set_chunk_events")
         del keep_k, keep_d
 
+    def _out_arrays(self, n_events: int, capacity: int, width: int, pinned: bool, reuse: bool):
+        """Output arrays of a delivered run: (offsets, rows [capacity, width], labels, event_points).
+        ``pinned``: page-locked memory (PCIe-rate copies).  ``reuse``: keep them for the next call of
+        the same shape -- the previous call's arrays are then overwritten."""
+        key = (n_events, capacity, width, pinned)
+        cached = getattr(self, "_out_cache", None)
+        if reuse and cached is not None and cached[0] == key:
+            return cached[1]
+        make = self.ctx.pinned_empty if pinned else (lambda shape, dtype: np.empty(shape, dtype=dtype))
+        arrays = (np.zeros(n_events + 1, dtype=np.int64), make((capacity, width), np.float64),
+                  make((capacity,), np.int64), np.zeros(n_events, dtype=np.int64))
+        self._out_cache = (key, arrays) if reuse else None
+        return arrays
+
     def run(self, n_events: int, seed: int = 0, first_event: int = 0, fetch: bool = False,
-            capacity_per_event: int = 12288) -> dict:
+            capacity_per_event: int = 12288, pinned: bool = False, reuse_buffers: bool = False) -> dict:
         """Simulate events ``first_event .. first_event + n_events - 1``.
 
         ``fetch=False``: everything stays device resident (chunk buffers are overwritten);
         only the statistics / checksums come back.  ``fetch=True``: also returns vertex, p4,
-        status and the point clouds in CSR form (offsets, points, labels)."""
+        status and the point clouds in CSR form (offsets, points, labels); ``pinned`` puts the cloud
+        arrays in page-locked host memory (the copy is PCIe bound), ``reuse_buffers`` reuses them
+        from call to call (a consumer that is done with one batch before it asks for the next).
+        Raises ``DataLossError`` if an event lost charge (``n_failed`` / ``n_inconsistent``)."""
         ctx = self.ctx
         stats = _abi.RunStats()
         if not fetch:
@@ -62,11 +79,9 @@ class Engine:
         status = np.empty(n_events, dtype=np.int32)
         capacity = max(4096, int(capacity_per_event) * int(n_events))
         while True:
-            offsets = np.zeros(n_events + 1, dtype=np.int64)
-            points = np.empty((capacity, 3), dtype=np.float64)
-            labels = np.empty(capacity, dtype=np.int64)
+            offsets, points, labels, event_points = self._out_arrays(n_events, capacity, 3, pinned, reuse_buffers)
             out = _abi.CloudOut(capacity, _abi.iptr(offsets, _abi.C.c_int64), _abi.dptr(points),
-                                _abi.iptr(labels, _abi.C.c_int64))
+                                _abi.iptr(labels, _abi.C.c_int64), _abi.iptr(event_points, _abi.C.c_int64))
             rc = ctx.lib.attpc_sim_run(ctx.handle, int(seed), int(first_event), int(n_events), self.layout,
                                        _abi.dptr(p4), _abi.dptr(vertex), _abi.iptr(status, _abi.C.c_int32),
                                        out, stats)
@@ -77,7 +92,7 @@ class Engine:
             break
         total = int(offsets[-1])
         return {"vertex": vertex, "p4": p4, "status": status, "offsets": offsets, "points": points[:total],
-                "labels": labels[:total], "stats": stats.as_dict()}
+                "labels": labels[:total], "event_points": event_points, "stats": stats.as_dict()}
 
     # ---------------------------------------------------------------- Spyral rows on the device
     def configure_spyral(self, config=None) -> None:
@@ -98,10 +113,13 @@ class Engine:
         ctx.check(ctx.lib.attpc_spyral_configure(ctx.handle, desc), "attpc_spyral_configure")
         self._spyral_configured = True
 
-    def run_spyral(self, n_events: int, seed: int = 0, first_event: int = 0, capacity_per_event: int = 6144) -> dict:
-        """Fused kinematics + detector + (on the device) GET response, ADC threshold and Spyral row
-        conversion.  Returns rows [P', 8] (x mm, y mm, z mm, amplitude, integral, pad, tb, pad scale)
-        in CSR form; rows of one event are in cloud order (sort by column 2 for the writer's z order)."""
+    def run_spyral(self, n_events: int, seed: int = 0, first_event: int = 0, capacity_per_event: int = 6144,
+                   pinned: bool = False, reuse_buffers: bool = False) -> dict:
+        """Fused kinematics + detector + (on the device) GET response, ADC threshold, Spyral row
+        conversion and z-sort.  Returns rows [P', 8] (x mm, y mm, z mm, amplitude, integral, pad, tb,
+        pad scale) in CSR form, the rows of every event in ascending z (reference writer.py:232-238), and
+        ``event_points`` [n] = cloud rows of every event before the threshold (an event is "empty" for
+        the writer only if that is 0, simulator.py:204-205)."""
         if not getattr(self, "_spyral_configured", False):
             self.configure_spyral()
         ctx = self.ctx
@@ -111,11 +129,9 @@ class Engine:
         status = np.empty(n_events, dtype=np.int32)
         capacity = max(4096, int(capacity_per_event) * int(n_events))
         while True:
-            offsets = np.zeros(n_events + 1, dtype=np.int64)
-            rows = np.empty((capacity, 8), dtype=np.float64)
-            labels = np.empty(capacity, dtype=np.int64)
+            offsets, rows, labels, event_points = self._out_arrays(n_events, capacity, 8, pinned, reuse_buffers)
             out = _abi.CloudOut(capacity, _abi.iptr(offsets, _abi.C.c_int64), _abi.dptr(rows),
-                                _abi.iptr(labels, _abi.C.c_int64))
+                                _abi.iptr(labels, _abi.C.c_int64), _abi.iptr(event_points, _abi.C.c_int64))
             rc = ctx.lib.attpc_sim_run_spyral(ctx.handle, int(seed), int(first_event), int(n_events), self.layout,
                                               _abi.dptr(p4), _abi.dptr(vertex), _abi.iptr(status, _abi.C.c_int32),
                                               out, stats)
@@ -126,22 +142,26 @@ class Engine:
             break
         total = int(offsets[-1])
         return {"vertex": vertex, "p4": p4, "status": status, "offsets": offsets, "rows": rows[:total],
-                "labels": labels[:total], "stats": stats.as_dict()}
+                "labels": labels[:total], "event_points": event_points, "stats": stats.as_dict()}
 
 
 def run_fused(pipeline, config, writer, n_events: int, indices: list[int] | None = None, seed: int | None = None,
               batch_size: int = 65536, context: _abi.Context | None = None) -> None:
     """run_kinematics_pipeline + run_simulation + SpyralWriter without the kinematics file and with
-    the response / threshold / row conversion done on the GPU: per non-empty event, in event order,
-    ``writer.write_rows(rows, labels, event_number)`` (rows already thresholded), then ``close()``."""
+    the response / threshold / row conversion / z-sort done on the GPU: per event with a non-empty
+    cloud (before the threshold, as simulator.py:204-205 decides it -- an event whose rows all fall
+    below the ADC threshold is still written, with 0 rows, and counts towards the file roll-over exactly
+    as in run_simulation + SpyralWriter.write), in event order,
+    ``writer.write_rows(rows, labels, event_number, presorted=True)``, then ``close()``."""
     engine = Engine(pipeline, config, indices, context=context)
     engine.configure_spyral(config)
     seed = pipeline.seed if seed is None else int(seed)
     for start in range(0, n_events, batch_size):
         n = min(batch_size, n_events - start)
         res = engine.run_spyral(n, seed=seed, first_event=start)
-        off = res["offsets"]
+        off, raw = res["offsets"], res["event_points"]
         for i in range(n):
-            if off[i + 1] > off[i]:
-                writer.write_rows(res["rows"][off[i]:off[i + 1]], res["labels"][off[i]:off[i + 1]], start + i)
+            if raw[i] > 0:
+                writer.write_rows(res["rows"][off[i]:off[i + 1]], res["labels"][off[i]:off[i + 1]], start + i,
+                                  presorted=True)
     writer.close()

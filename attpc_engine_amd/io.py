@@ -17,12 +17,28 @@ def _h5py():
         return None
 
 
+def hdf5_or_fallback(path: Path, npz_fallback: bool):
+    """h5py if it is importable; otherwise ``None`` after a warning that ``path`` is written as
+    ``.npz`` (which the reference and Spyral cannot read), or ImportError when the fallback was declined."""
+    h5 = _h5py()
+    if h5 is None:
+        message = (f"h5py is not installed: {path} cannot be written as HDF5; the same datasets go to "
+                   f"{Path(path).with_suffix('.npz')} (not readable by the reference / Spyral tooling)")
+        if not npz_fallback:
+            raise ImportError(message + " -- install h5py or pass npz_fallback=True")
+        import warnings
+
+        warnings.warn(message, RuntimeWarning, stacklevel=3)
+    return h5
+
+
 class KinematicsFileWriter:
-    def __init__(self, path: Path, n_events: int, proton_numbers, mass_numbers, chunk_size: int):
+    def __init__(self, path: Path, n_events: int, proton_numbers, mass_numbers, chunk_size: int,
+                 npz_fallback: bool = True):
         self.path = Path(path)
         self.n_events = int(n_events)
         self.chunk_size = int(chunk_size)
-        self.h5 = _h5py() if self.path.suffix.lower() in (".h5", ".hdf5") else None
+        self.h5 = hdf5_or_fallback(self.path, npz_fallback) if self.path.suffix.lower() in (".h5", ".hdf5") else None
         self.z = np.asarray(proton_numbers)
         self.a = np.asarray(mass_numbers)
         if self.h5 is not None:

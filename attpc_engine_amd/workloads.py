@@ -17,10 +17,10 @@ from .kinematics import (
 )
 
 
-def detector_config(gas, diffusion: float = 0.277) -> Config:
+def detector_config(gas, diffusion: float = 0.277, path_step: float = 0.0) -> Config:
     """Detector/electronics defaults of the reference's own test (tests/test_detector.py:15-33)."""
     det = DetectorParams(length=1.0, efield=45000.0, bfield=2.85, mpgd_gain=175000, gas_target=gas,
-                         diffusion=diffusion, fano_factor=0.2, w_value=34.0)
+                         diffusion=diffusion, fano_factor=0.2, w_value=34.0, path_step=path_step)
     elec = ElectronicsParams(clock_freq=6.25, amp_gain=900, shaping_time=1000, micromegas_edge=10,
                              windows_edge=560, adc_threshold=40)
     return Config(det, elec, PadParams())
@@ -61,10 +61,12 @@ def o16aa(seed: int = 3, **kw):
     return pipeline, detector_config(gas), default_indices(6)
 
 
-def b10chain(seed: int = 5, diffusion: float = 2.77, **kw):
-    """configs[4] (stress): the 3-step chain of the reference's test_pipeline
-    (tests/test_kinematics.py:42-69) 10B(3He,a)9B -> a + 5Li -> a + p at 24 MeV in He 600 Torr,
-    10x the default diffusion coefficient to maximise scatter contention; indices [2,4,6,7]."""
+def b10chain(seed: int = 5, diffusion: float = 2.77, path_step: float = 1.0e-4, **kw):
+    """configs[4] (stress): 3-step chain 10B(3He,a)9B -> a + 5Li -> a + p, 24 MeV 3He, He 600 Torr, 0.1 mm dE/dx path step, 10x diffusion, indices [2,4,6,7]
+    (the chain of the reference's test_pipeline, tests/test_kinematics.py:42-69; ``path_step`` and the
+    diffusion are the stress extensions BASELINE.json names: a track sample every 0.1 mm of arc
+    length instead of the reference's 1e-10 s grid, and 10x the default diffusion coefficient to
+    maximise scatter contention)."""
     nm = nuclear_map
     gas = GasTarget([(2, 4, 1)], 600.0, nm)
     pipeline = KinematicsPipeline(
@@ -74,7 +76,7 @@ def b10chain(seed: int = 5, diffusion: float = 2.77, **kw):
         [ExcitationGaussian(16.8, 0.2), ExcitationGaussian(0.0, 1.25), ExcitationGaussian(0.0, 0.0)],
         [PolarUniform(0.0, np.pi)] * 3, beam_energy=24.0,
         target_material=KinematicsTargetMaterial(gas, (0.0, 1.0), 0.007), seed=seed, **kw)
-    return pipeline, detector_config(gas, diffusion=diffusion), default_indices(8)
+    return pipeline, detector_config(gas, diffusion=diffusion, path_step=path_step), default_indices(8)
 
 
 WORKLOADS = {"c12pp": c12pp, "be10dp": be10dp, "o16aa": o16aa, "b10chain": b10chain}

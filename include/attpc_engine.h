@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ATTPC_ABI_VERSION 1
+#define ATTPC_ABI_VERSION 2
 #define ATTPC_API __attribute__((visibility("default")))
 
 /* status codes */
@@ -38,6 +38,8 @@ extern "C" {
 #define ATTPC_E_HIP 3           /* a HIP runtime call failed (see attpc_last_error)         */
 #define ATTPC_E_CAPACITY 4      /* caller buffer too small; required size in stats          */
 #define ATTPC_E_NOTCONFIGURED 5 /* run called before the matching configure                 */
+#define ATTPC_E_DATALOSS 6      /* the run finished but stats.n_failed or stats.n_inconsistent is
+                                   not 0: part of an event's charge is missing from the cloud     */
 
 #define ATTPC_MAX_STEPS 8    /* 1 Reaction + up to 7 Decays                                 */
 #define ATTPC_MAX_ROWS (4 + 2 * (ATTPC_MAX_STEPS - 1)) /* nuclei (rows) per event           */
@@ -144,6 +146,14 @@ typedef struct attpc_det_desc {
      0 = the reference's mesh. */
   int32_t mc_diffusion;
   int32_t reserved_ext;
+  /* EXTENSION (BASELINE configs[4] "0.1 mm dE/dx step"; the reference grid is fixed in time,
+     detector/solver.py:16,285-303): > 0 records a track sample -- and creates its electrons from the
+     energy lost since the previous sample, solver.py:338-346 -- every `path_step` metres of arc length:
+     sample k+1 follows sample k after the time min(path_step / v_k, 1e-10 s) (v_k = speed at sample k;
+     never coarser than the reference grid, so the end of the range is integrated as in the default
+     mode), each interval integrated with ode_substeps RK4 steps; recording ends with the reference's
+     1 us window or after ATTPC_TIME_SAMPLES samples.  0 = the reference's 1e-10 s grid. */
+  double path_step; /* m */
 } attpc_det_desc;
 
 /* which rows of an event are simulated, detector/simulator.py:96-101,157-158 */
@@ -160,6 +170,8 @@ typedef struct attpc_cloud_out {
   int64_t* offsets;   /* [n_events + 1] CSR offsets into points/labels */
   double* points;     /* [capacity, 3] rows (pad, time bucket, electrons) -- simulator.py:40-46 */
   int64_t* labels;    /* [capacity] row index of the nucleus that last touched the point */
+  int64_t* event_points; /* [n_events] or NULL: cloud rows of every event BEFORE any threshold
+                            (simulator.py:204-205 decides "empty event" on this count) */
 } attpc_cloud_out;
 
 typedef struct attpc_run_stats {
@@ -168,7 +180,8 @@ typedef struct attpc_run_stats {
   uint64_t n_track_samples;   /* track samples with >= 1 electron (scatter work items) */
   uint64_t n_sample_limit;    /* events that hit event_sample_limit */
   uint64_t n_lds_overflow;    /* windows redone with a smaller time-bucket range (LDS table too full) */
-  uint64_t n_failed;          /* events with a single time bucket larger than the LDS table (bucket dropped) */
+  uint64_t n_failed;          /* events that lost a time bucket (more than 65 536 lone buckets in one launch);
+                                 must be 0 -- the run then returns ATTPC_E_DATALOSS */
   uint64_t charge_checksum;   /* sum of all charges mod 2^64 */
   uint64_t key_checksum;      /* sum over points of (event*2^24 + tb*2^14 + pad) mod 2^64 */
   double ms_kinematics;       /* device time of each kernel family (HIP events on the ctx stream) */
@@ -179,6 +192,8 @@ typedef struct attpc_run_stats {
   uint32_t launches_scatter;
   uint32_t n_inconsistent;    /* self-check: flushed windows whose occupied-slot count differed from the
                                  number of claimed keys; must be 0 */
+  uint64_t n_lone_buckets;    /* time buckets that alone exceeded the LDS table and went through the
+                                 direct-mapped table of lone_bucket_kernel (complete, just slower) */
 } attpc_run_stats;
 
 typedef struct attpc_ctx attpc_ctx;
@@ -192,6 +207,18 @@ ATTPC_API const char* attpc_last_error(const attpc_ctx* ctx);
 /* events processed per internal chunk (device working set scales with it); 0 -> default */
 ATTPC_API int32_t attpc_set_chunk_events(attpc_ctx* ctx, int32_t chunk_events);
 ATTPC_API int32_t attpc_sync(attpc_ctx* ctx);
+/* Tuning / test switches of a context (no environment variables are read by the library):
+ *   "scatter_variant"  0 = automatic, 1 = always the two-workgroups-per-CU build, 2 = always the
+ *                      one-workgroup build of the scatter kernel
+ *   "tiny_buffers"     != 0: the next buffers are allocated far too small (exercises the
+ *                      grow-and-rerun path in tests)
+ *   "chunk_events"     as attpc_set_chunk_events */
+ATTPC_API int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value);
+/* Page-locked host memory for output buffers (point clouds are PCIe bound on their way to the host:
+ * copies into pinned memory run at the link rate, copies into pageable memory at a fraction of it).
+ * Plain memory otherwise: the caller reads/writes it freely and returns it with attpc_host_free. */
+ATTPC_API int32_t attpc_host_alloc(attpc_ctx* ctx, uint64_t bytes, void** out);
+ATTPC_API int32_t attpc_host_free(attpc_ctx* ctx, void* ptr);
 
 /* KinematicsPipeline(...) state -> device.  kinematics/pipeline.py:125-185 */
 ATTPC_API int32_t attpc_kin_configure(attpc_ctx* ctx, const attpc_kin_desc* desc);
@@ -247,6 +274,18 @@ ATTPC_API int32_t attpc_det_tracks(attpc_ctx* ctx, uint64_t seed, uint64_t first
                          const double* vertex, int64_t max_samples_per_track, double* samples,
                          int32_t* counts, int32_t* n_steps);
 
+/* Diagnostics used by the parity tests: the pad-plane scatter alone -- transport_track
+ * (detector/transporter.py:252-317: transverse_transport :172-249, point_transport :123-169,
+ * position_to_index :78-120) per simulated nucleus into the event's shared dictionary, then
+ * dict_to_points + jitter + 0 <= tb < 512 mask (detector/simulator.py:19-49, :93-113) -- for EXPLICIT
+ * track samples, so that reference-generated transport fixtures reach the HIP kernel directly.
+ * samples [sum(counts), 4] rows (x m, y m, time bucket, electrons already multiplied by the gain),
+ * concatenated track by track, track = event * n_sim + position in layout->indices;
+ * counts [n_events * n_sim] (each <= 10112).  layout->species_of_row is ignored. */
+ATTPC_API int32_t attpc_det_scatter(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                          const attpc_event_layout* layout, const double* samples, const int32_t* counts,
+                          attpc_cloud_out* out, attpc_run_stats* stats);
+
 /* GET response + Spyral row conversion, detector/response.py:8-57, detector/writer.py:61-112:
  * rows [n,8] = x_mm, y_mm, z_mm, amplitude, integral, pad, tb, pad_scale. */
 ATTPC_API int32_t attpc_spyral_rows(attpc_ctx* ctx, int64_t n_points, const double* points,
@@ -272,9 +311,9 @@ ATTPC_API int32_t attpc_spyral_configure(attpc_ctx* ctx, const attpc_spyral_desc
 
 /* attpc_sim_run followed, on the device and before anything crosses PCIe, by what SpyralWriter.write
  * does per event (detector/writer.py:194-238): convert_to_spyral (rows of 8: x_mm, y_mm, z_mm,
- * amplitude, integral, pad, tb, pad_scale) and the ADC-threshold cut.  out->points receives rows of
- * EIGHT doubles here (capacity counts rows); rows of one event keep their cloud order (the z-sort of
- * writer.py:236-238 is left to the host writer). */
+ * amplitude, integral, pad, tb, pad_scale), the ADC-threshold cut (:232-234) and the sort by z
+ * (:236-238).  out->points receives rows of EIGHT doubles here (capacity counts rows), the rows of
+ * every event in ascending z, ready for the writer. */
 ATTPC_API int32_t attpc_sim_run_spyral(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
                                        const attpc_event_layout* layout, double* p4, double* vertex,
                                        int32_t* kin_status, attpc_cloud_out* out, attpc_run_stats* stats);

@@ -371,7 +371,13 @@ int32_t orc_generate_trajectory(const orc_det_desc* det, const orc_species_desc*
   double gv0 = sqrt(s[3] * s[3] + s[4] * s[4] + s[5] * s[5]);
   if (!(gv0 > 0.0) || !isfinite(gv0)) return 1; /* nothing to integrate */
   int nsub = det->ode_substeps > 0 ? det->ode_substeps : 1;
-  double h = 1.0e-10 / (double)nsub;
+  /* EXTENSION (path_step > 0, no reference counterpart: the reference grid is fixed in time,
+   * solver.py:16): a sample every `path_step` metres of arc length, i.e. after the time
+   * path_step / v(state at the previous sample), but never coarser than the reference's own
+   * 1e-10 s grid (so the end of the range is integrated exactly like the default mode);
+   * recording stops with the reference's 1 us window and its 10001-sample cap. */
+  const int by_path = det->path_step > 0.0;
+  double h_sample = 1.0e-10, t = 0.0;
   double bf = det->bfield * -1.0, ef = det->efield * -1.0; /* solver.py:297-299 */
   double g_ke = kinetic_energy(s, sp->mass) - KE_LIMIT;
   double g_zf = s[2] - 1.0;
@@ -379,6 +385,14 @@ int32_t orc_generate_trajectory(const orc_det_desc* det, const orc_species_desc*
   double g_rho = sqrt(s[0] * s[0] + s[1] * s[1]) - 0.292;
   int32_t n = 1;
   for (int k = 1; k < ORC_TIME_SAMPLES; ++k) {
+    if (by_path) {
+      double gv2 = s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
+      double v = C_LIGHT * sqrt(gv2 / (1.0 + gv2));
+      h_sample = det->path_step / v;
+      if (!(h_sample < 1.0e-10)) h_sample = 1.0e-10;
+      if (t + h_sample > 1.0e-6 * (1.0 + 1.0e-9)) break; /* end of the recording window */
+    }
+    double h = h_sample / (double)nsub;
     int stop = 0;
     for (int sub = 0; sub < nsub && !stop; ++sub) {
       double k1[6], k2[6], k3[6], k4[6], y[6];
@@ -403,6 +417,7 @@ int32_t orc_generate_trajectory(const orc_det_desc* det, const orc_species_desc*
       g_ke = n_ke; g_zf = n_zf; g_zb = n_zb; g_rho = n_rho;
     }
     if (stop) break;
+    t += h_sample;
     memcpy(track + (size_t)n * 6, s, sizeof s);
     n++;
   }

@@ -76,6 +76,7 @@ typedef struct {
   double long_weights[5];
   int32_t mc_diffusion;          /* extension: per-electron Monte-Carlo transverse diffusion */
   int32_t reserved_ext;
+  double path_step;              /* extension: track sample every path_step metres (0 = 1e-10 s grid) */
 } orc_det_desc;
 
 typedef struct {

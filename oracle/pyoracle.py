@@ -191,6 +191,13 @@ def transport(det: _abi.DetDesc, cases):
     return keys, charge, labels
 
 
+def unpair(key: int) -> tuple[int, int]:
+    """(time bucket, pad) of a dictionary key (reference pairing.py:30-55)."""
+    tb, pad = C.c_int64(), C.c_int64()
+    lib().orc_unpair(int(key), C.byref(tb), C.byref(pad))
+    return tb.value, pad.value
+
+
 def point_cloud_samples(det: _abi.DetDesc, species_index: int, momentum, vertex, seed: int, event: int,
                         label: int):
     """kept samples [m,4] (x, y, time bucket, electrons*gain) and the number of ODE rows."""

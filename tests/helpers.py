@@ -13,7 +13,10 @@ class Inputs:
     has the unfolded LUT (the oracle applies the beam-pad list itself)."""
 
     def __init__(self, name: str, ode_substeps: int = 1, **kw):
+        det_overrides = {k: kw.pop(k) for k in ("path_step",) if k in kw}  # DetectorParams fields, any workload
         self.pipeline, self.config, self.indices = workloads.WORKLOADS[name](**kw)
+        for key, value in det_overrides.items():
+            setattr(self.config.det_params, key, value)
         self.kin, self._k1 = self.pipeline.device_desc()
         self.z = self.pipeline.get_proton_numbers()
         self.a = self.pipeline.get_mass_numbers()
@@ -34,7 +37,7 @@ def sort_cloud(points: np.ndarray, labels: np.ndarray):
     return points[order], labels[order]
 
 
-def compare_clouds(pts_a, lab_a, pts_b, lab_b, charge_tol: float = 8.0):
+def compare_clouds(pts_a, lab_a, pts_b, lab_b, charge_tol: float = 2.0):
     """Both sorted.  Keys, labels and jittered time buckets must agree exactly; charges to
     within ``charge_tol`` electrons (integer truncation of a product that differs in the
     last bits between host libm and device libm, see DESIGN.md "Tolerances")."""

@@ -4,8 +4,9 @@ golden vectors of the reference.  Needs a real MI355X: run with ``-m gpu``.
 Tolerances (north star: "within a stated FP tolerance"):
   * 4-vectors: 1e-9 MeV absolute (values up to 1.5e4 MeV), vertices 1e-12 m
   * track samples: x, y 1e-9 m; time bucket 1e-7; electron counts equal
-  * cloud: identical key set, labels and jittered time buckets; charges within 8 electrons
-    (integer truncation of products whose last bits differ between glibc and device libm)
+  * cloud: identical key set, labels and jittered time buckets; charges within 2 electrons
+    (integer truncation of products whose last bits differ between glibc and device libm;
+    largest difference ever observed: 1)
 """
 import numpy as np
 import pytest
@@ -166,10 +167,12 @@ def _device_tracks(ctx, inp, p4, vertex, seed, first):
     return samples, counts, steps
 
 
-@pytest.mark.parametrize("name", ["o16aa", "be10dp"])
-def test_tracks_vs_oracle(ctx, orc, name):
-    inp = Inputs(name)
-    n, seed, first = 24, 21, 1000
+@pytest.mark.parametrize("name,kw,n", [("o16aa", {}, 24), ("be10dp", {}, 24),
+                                       # path-length sampling extension (BASELINE configs[4]: 0.1 mm dE/dx step)
+                                       ("b10chain", {"path_step": 1.0e-4}, 6), ("o16aa", {"path_step": 2.5e-4}, 8)])
+def test_tracks_vs_oracle(ctx, orc, name, kw, n):
+    inp = Inputs(name, **kw)
+    seed, first = 21, 1000
     vertex, p4, _, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
     samples, counts, steps = _device_tracks(ctx, inp, p4, vertex, seed, first)
     mismatched = 0
@@ -225,11 +228,12 @@ def test_long_and_degenerate_tracks(ctx, orc):
     assert steps[0] > 500 and steps[4 * 2] == 1
 
 
-@pytest.mark.parametrize("name,n", [("o16aa", 24), ("be10dp", 24), ("b10chain", 8)])
-def test_det_run_vs_oracle(ctx, orc, name, n):
+@pytest.mark.parametrize("name,n,kw", [("o16aa", 24, {}), ("be10dp", 24, {}), ("b10chain", 8, {"path_step": 0.0}),
+                                       ("b10chain", 6, {})])  # configs[4] as written: 0.1 mm path step + 10x diffusion
+def test_det_run_vs_oracle(ctx, orc, name, n, kw):
     """simulate() per event through attpc_det_run vs the oracle's orc_simulate."""
     from attpc_engine_amd.detector.simulator import simulate_batch
-    inp = Inputs(name)
+    inp = Inputs(name, **kw)
     seed, first = 77, 5
     vertex, p4, status, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
     offsets, points, labels, stats = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, seed, inp.indices,
@@ -370,14 +374,16 @@ def test_sim_run_vs_oracle(ctx, orc, name, n):
     st = res["stats"]
     assert st["n_points"] == ref["stats"][0] and st["n_track_samples"] == ref["stats"][1]
     assert st["key_checksum"] == ref["stats"][3]
-    assert abs(int(st["charge_checksum"]) - int(ref["stats"][2])) <= 8 * st["n_points"]
+    # <= 2 electrons on a point whose pixel truncation flipped, and such points are rarer than 1 in 10^4
+    assert abs(int(st["charge_checksum"]) - int(ref["stats"][2])) <= 2 * max(8, st["n_points"] // 10_000)
 
 
-def test_multichunk_assembly_and_buffer_growth(orc, monkeypatch):
-    """Tiny chunks (host CSR assembly across chunks and windows) and deliberately undersized
-    device buffers (arena / cloud / segment list grow-and-rerun path) give the same clouds."""
-    monkeypatch.setenv("ATTPC_TEST_TINY_BUFFERS", "1")
+def test_multichunk_assembly_and_buffer_growth(orc):
+    """Tiny chunks (device CSR assembly across chunks and windows, two assembly sets in flight) and
+    deliberately undersized device buffers (arena / cloud / segment list grow-and-rerun path) give the
+    same clouds."""
     fresh = _abi.Context(0)
+    fresh.set_option("tiny_buffers", 1)
     inp = Inputs("o16aa")
     eng = _engine(inp, fresh, chunk_events=7)
     n = 40
@@ -404,7 +410,7 @@ def test_bulk_checksums_vs_oracle(ctx, orc, name, n):
     assert st["n_points"] == ref[0] and st["n_track_samples"] == ref[1]
     assert st["key_checksum"] == ref[3] % (1 << 64)
     diff = (int(st["charge_checksum"]) - int(ref[2] % (1 << 64)) + (1 << 63)) % (1 << 64) - (1 << 63)
-    assert abs(diff) <= 8 * st["n_points"], diff
+    assert abs(diff) <= 2 * max(8, st["n_points"] // 10_000), diff  # see test_sim_run_vs_oracle
     assert st["n_failed"] == 0 and st["n_inconsistent"] == 0
     print(name, "points", st["n_points"], "charge checksum difference (electrons)", diff)
 
@@ -425,7 +431,8 @@ def test_invariance_chunks_shards_residency(ctx):
     small = eng3.run(n, seed=8, first_event=0)["stats"]
     for k in ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_sample_limit"):
         assert whole[k] == small[k], k
-    assert small["launches_tracks"] == 4 and small["launches_scatter"] == 30
+    # track batches: one chunk first (nothing to hide it behind), then 8 chunks each: 100 + 3 x 800 + 500
+    assert small["launches_tracks"] == 5 and small["launches_scatter"] == 30
     a = eng2.run(n // 2, seed=8, first_event=0)["stats"]
     b = eng2.run(n - n // 2, seed=8, first_event=n // 2)["stats"]
     assert a["n_points"] + b["n_points"] == whole["n_points"]
@@ -462,17 +469,17 @@ def test_full_size_properties(ctx):
     assert (res["points"][:, 2] >= 0).all()
 
 
-def test_kernel_variants_agree_and_small_falls_back(monkeypatch):
+def test_kernel_variants_agree():
     """The scatter kernel exists in two builds (one 1024-thread workgroup with 8192 table slots per
     CU, two 512-thread workgroups with 4096); the host picks one per launch.  Both give the same
-    clouds, and a chunk the small one cannot hold (10x diffusion: a time bucket with more than 4096
-    keys) is run again with the big one without losing a point."""
+    clouds -- also where the small table meets time buckets it cannot hold (10x diffusion), which then
+    go through lone_bucket_kernel without losing a point."""
     stats = {}
-    for variant in ("big", "small"):
-        monkeypatch.setenv("ATTPC_SC_VARIANT", variant)
+    for variant, code in (("big", 2), ("small", 1)):
         fresh = _abi.Context(0)
+        fresh.set_option("scatter_variant", code)
         for name, n in (("o16aa", 3000), ("b10chain", 1500)):
-            inp = Inputs(name)
+            inp = Inputs(name, **({"path_step": 0.0} if name == "b10chain" else {}))
             eng = _engine(inp, fresh)
             stats[variant, name] = eng.run(n, seed=5, first_event=11)["stats"]
         fresh.close()
@@ -481,7 +488,8 @@ def test_kernel_variants_agree_and_small_falls_back(monkeypatch):
         for k in ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_failed", "n_inconsistent"):
             assert a[k] == b[k], (name, k)
         assert a["n_failed"] == 0 and a["n_inconsistent"] == 0
-    assert stats["small", "b10chain"]["launches_scatter"] >= 1
+    print("lone buckets (big / small, b10chain):", stats["big", "b10chain"]["n_lone_buckets"],
+          stats["small", "b10chain"]["n_lone_buckets"])
 
 
 def test_fetch_with_block_reserved_rows(ctx):
@@ -503,6 +511,34 @@ def test_fetch_with_block_reserved_rows(ctx):
         assert len(np.unique(k)) == len(k)
     resident = eng.run(n, seed=12, first_event=77)["stats"]
     assert resident["key_checksum"] == st["key_checksum"] and resident["charge_checksum"] == st["charge_checksum"]
+
+
+def test_pinned_delivery_and_buffer_reuse(ctx):
+    """Clouds delivered into page-locked arrays (attpc_host_alloc) over several chunks, with the two
+    assembly sets in flight and the arrays reused from call to call: identical to the pageable path."""
+    inp = Inputs("be10dp")
+    eng = _engine(inp, ctx, chunk_events=300)
+    n = 2000
+    plain = eng.run(n, seed=8, first_event=50, fetch=True)
+    a = eng.run(n, seed=8, first_event=50, fetch=True, pinned=True, reuse_buffers=True)
+    np.testing.assert_array_equal(a["offsets"], plain["offsets"])
+
+    def canonical(res):  # rows of an event come in hash order: sort by (event, pad, time bucket)
+        ev = np.repeat(np.arange(n), np.diff(res["offsets"]))
+        order = np.lexsort((res["points"][:, 1], res["points"][:, 0], ev))
+        return res["points"][order], res["labels"][order]
+
+    pa, la = canonical(a)
+    pp, lp = canonical(plain)
+    np.testing.assert_array_equal(pa, pp)
+    np.testing.assert_array_equal(la, lp)
+    np.testing.assert_array_equal(a["event_points"], np.diff(plain["offsets"]))
+    keep = a["points"]
+    b = eng.run(n, seed=9, first_event=50, fetch=True, pinned=True, reuse_buffers=True)
+    assert np.shares_memory(keep, b["points"])  # reused, as asked for
+    assert b["stats"]["charge_checksum"] != plain["stats"]["charge_checksum"]
+    st = b["stats"]
+    assert int(b["points"][:, 2].astype(np.uint64).sum()) % (1 << 64) == st["charge_checksum"]
 
 
 def test_empty_and_errors(ctx):
@@ -629,8 +665,9 @@ def test_reaction_errors_and_config_paths(tmp_path, ctx):
 
 
 def test_fused_spyral_rows(tmp_path, ctx, orc):
-    """attpc_sim_run_spyral (response, ADC threshold, row conversion on the device) against
-    (a) the cloud path + convert_to_spyral + threshold and (b) the oracle's convert_to_spyral."""
+    """attpc_sim_run_spyral (response, ADC threshold, row conversion, z-sort on the device) against
+    (a) the cloud path + convert_to_spyral + threshold + argsort(z) and (b) the oracle's convert_to_spyral;
+    then the writer integration, also where the threshold removes every row of an event."""
     from attpc_engine_amd.detector.response import get_response
     from attpc_engine_amd.detector.writer import SpyralWriter, convert_to_spyral
     from attpc_engine_amd.engine import run_fused
@@ -652,9 +689,16 @@ def test_fused_spyral_rows(tmp_path, ctx, orc):
         flo, fhi = fused["offsets"][e], fused["offsets"][e + 1]
         got, got_lab = fused["rows"][flo:fhi], fused["labels"][flo:fhi]
         assert len(got) == keep.sum()
-        # both are in cloud order of their own run: compare sorted by (pad, tb)
-        o1 = np.lexsort((got[:, 6], got[:, 5]))
+        assert fused["event_points"][e] == hi - lo  # rows before the threshold (what "empty event" is decided on)
+        # the device delivers what SpyralWriter.write builds (writer.py:232-238): threshold, then argsort of z
         want, want_lab = rows[keep], lab[keep]
+        zorder = np.argsort(want[:, 2], kind="stable")
+        assert (np.diff(got[:, 2]) >= 0).all()
+        np.testing.assert_array_equal(got[:, 2], want[zorder][:, 2])
+        np.testing.assert_array_equal(got[:, [5, 6]], want[zorder][:, [5, 6]])  # z values are distinct: same rows in the same order
+        np.testing.assert_array_equal(got_lab, want_lab[zorder])
+        # (and the old order-free comparison of all eight columns)
+        o1 = np.lexsort((got[:, 6], got[:, 5]))
         o2 = np.lexsort((want[:, 6], want[:, 5]))
         np.testing.assert_allclose(got[o1], want[o2], rtol=1e-12, atol=0)
         np.testing.assert_array_equal(got[o1][:, [0, 1, 2, 3, 5, 6, 7]], want[o2][:, [0, 1, 2, 3, 5, 6, 7]])
@@ -677,6 +721,34 @@ def test_fused_spyral_rows(tmp_path, ctx, orc):
         assert names
         rows0 = first[names[0]]
         assert rows0.shape[1] == 8 and (np.diff(rows0[:, 2]) >= 0).all() and (rows0[:, 3] > thr).all()
+    # with a threshold nothing survives, run_fused must still write the same (empty) datasets
+    # and roll files over at the same events as run_simulation + SpyralWriter.write
+    import copy
+    import warnings
+    high = copy.copy(cfg)
+    high.elec_params = copy.copy(cfg.elec_params)
+    high.elec_params.adc_threshold = 5000  # above the 4095 clip: every row goes
+
+    class Log:
+        def __init__(self):
+            self.calls = []
+
+        def write_rows(self, rows, labels, event_number, presorted=False):
+            self.calls.append((event_number, len(rows), presorted))
+
+        def get_directory_name(self):
+            return tmp_path
+
+        def close(self):
+            self.calls.append("closed")
+
+    log = Log()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        run_fused(inp.pipeline, high, log, n, seed=77, context=ctx)
+    raw0 = eng.run_spyral(n, seed=77, first_event=0)["event_points"]  # run_fused numbers its events from 0
+    assert log.calls[-1] == "closed" and [c[0] for c in log.calls[:-1]] == [e for e in range(n) if raw0[e] > 0]
+    assert all(c[1] == 0 and c[2] for c in log.calls[:-1]) and len(log.calls) > n // 2
 
 
 def test_spyral_rows_golden(golden_dir, ctx):

@@ -748,15 +748,15 @@ int32_t run_events(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t
   int64_t row_cursor = 0;
   bool over = false;
   if (out && out->offsets) out->offsets[0] = 0;
-  // the first batch is one chunk (its tracks cannot hide behind a scatter), the following ones up to
-  // MAX_SLOTS chunks, each integrated on T while the previous batch is scattered on S
+  // batches of up to MAX_SLOTS chunks (a small pilot batch while the arena need per track is unknown),
+  // each integrated on T while the previous batch is scattered on S
   uint64_t b0 = 0;
   int cur = 0;
   TrackLaunch tl[2];
   auto batch_size = [&](uint64_t at) -> uint32_t {
     const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events);
     uint64_t want = track_batch_events(ctx, lay, chunk);
-    if (at == 0) want = std::min<uint64_t>(want, ctx->blocks_per_track > 0.0 ? chunk : std::min<uint64_t>(chunk, 16384));
+    if (ctx->blocks_per_track <= 0.0) want = std::min<uint64_t>(want, std::min<uint64_t>(chunk, 16384));  // pilot: sizes the arena
     return (uint32_t)std::min<uint64_t>(want, n_events - at);
   };
   uint32_t nb = n_events ? batch_size(0) : 0;

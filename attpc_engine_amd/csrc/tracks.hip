@@ -288,8 +288,8 @@ __global__ __launch_bounds__(TRACK_THREADS) void track_kernel(TrackArgs a) {
           const double tb = (a.det.length - s[2]) * a.det.inv_dv + a.det.mm_edge;  // solver.py:395-398
           reinterpret_cast<double2*>(o)[0] = make_double2(s[0], s[1]);
           reinterpret_cast<double2*>(o)[1] = make_double2(tb, (double)(n_el * a.det.mpgd_gain));
-          count++;
         }
+        count++;  // also without a block: the block counter then tells the host exactly how large the arena must be
       }
       if (active) {
         if (!stop && k >= ATTPC_TIME_SAMPLES - 1) stop = true;  // t = 1 us: last recorded sample

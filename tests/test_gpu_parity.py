@@ -431,7 +431,7 @@ def test_invariance_chunks_shards_residency(ctx):
     small = eng3.run(n, seed=8, first_event=0)["stats"]
     for k in ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_sample_limit"):
         assert whole[k] == small[k], k
-    # track batches: one chunk first (nothing to hide it behind), then 8 chunks each: 100 + 3 x 800 + 500
+    # track batches: a pilot of one chunk (a new Engine resets the arena estimate), then 8 chunks each: 100 + 3 x 800 + 500
     assert small["launches_tracks"] == 5 and small["launches_scatter"] == 30
     a = eng2.run(n // 2, seed=8, first_event=0)["stats"]
     b = eng2.run(n - n // 2, seed=8, first_event=n // 2)["stats"]

@@ -458,8 +458,8 @@ int32_t enqueue_scatter(attpc_ctx* ctx, int slot, const attpc_event_layout& lay,
 #ifdef ATTPC_PHASE_TIMERS
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   const unsigned long long* octrl = ctx->h_out_ctrl + (size_t)slot * CTRL_WORDS;
-  fprintf(stderr, "[attpc phase cycles] init %llu hist %llu select %llu stage %llu items %llu overflow %llu flushcount %llu flushwrite %llu (events %u)\n",
-          octrl[8], octrl[9], octrl[10], octrl[11], octrl[12], octrl[13], octrl[14], octrl[15], n);
+  fprintf(stderr, "[attpc phase cycles] init %llu hist %llu select %llu stage %llu items %llu insert-calls %llu insert-trips %llu flushcount %llu flushwrite %llu (events %u)\n",
+          octrl[8], octrl[9], octrl[10], octrl[11], octrl[12], octrl[13] >> 32, octrl[13] & 0xffffffffull, octrl[14], octrl[15], n);
   fprintf(stderr, "[attpc rows-phase cycles] gathers %llu runs %llu scan+queue %llu drain %llu\n", octrl[16], octrl[17], octrl[18], octrl[19]);
   fprintf(stderr, "[attpc rounds] rows-rounds %llu staged %llu busiest-wave passes %llu\n", octrl[20], octrl[21], octrl[22]);
   fprintf(stderr, "[attpc flush cycles] to-barrier %llu to-compacted %llu atomics-wait %llu segment %llu select %llu barrier %llu\n", octrl[27], octrl[23], octrl[24], octrl[25], octrl[26], octrl[14]);

@@ -22,8 +22,9 @@
 //          read neighbouring addresses), the 10 pixel charges truncated to u32, runs of equal pads
 //          merged in registers, runs (key|label, charge) written to the wave's LDS queue at positions
 //          from a ballot prefix
-//   insert (same wave) one lane per queued run in one wave-uniform loop: ds_read_b128 bucket probe,
-//          ds_cmpst_b32 to claim a slot, ds_max_u32 for the label, ds_add_u64 for the charge
+//   insert (same wave) the queued runs as a stream, one probe step per lane and trip: ds_read_b128 bucket
+//          probe, ds_cmpst_b32 to claim a slot, ds_max_u32 for the label, ds_add_u64 for the charge; a lane
+//          that is done takes the next run at once
 //   flush  occupied slots compacted per wave, rows written (with the Philox time-bucket jitter) to a
 //          range of the output block this workgroup reserved, slots reset on the way
 // Merging before inserting cuts hash inserts ~7x (100 pixels -> ~15 pads per sample) and the
@@ -269,12 +270,13 @@ __device__ __forceinline__ bool table_add(ScatterShared& sh, uint32_t want, unsi
 // at most one compare-and-swap, and the two fire-and-forget updates.  `claimed` counts the new
 // keys of the wave (scalar).  False if some lane ran out of probes.
 __device__ __forceinline__ bool wave_insert(ScatterShared& sh, uint32_t want, uint32_t q, bool pending,
-                                            unsigned int& claimed) {
+                                            unsigned int& claimed, unsigned int& trips) {
   const uint32_t key = want & KEY_MASK;
   uint32_t b = hash_bucket(key);
   int probes = 0;
   bool fail = false;
   while (__any(pending)) {
+    trips++;  // diagnostic builds only (dead code otherwise)
     const uint4 k4 = *reinterpret_cast<const uint4*>(&sh.keys[b * BUCKET]);
     const bool m0 = (k4.x & KEY_MASK) == key, m1 = (k4.y & KEY_MASK) == key;
     const bool m2 = (k4.z & KEY_MASK) == key, m3 = (k4.w & KEY_MASK) == key;
@@ -302,6 +304,71 @@ __device__ __forceinline__ bool wave_insert(ScatterShared& sh, uint32_t want, ui
     fail = fail || give_up;
     b = advance ? ((b + 1) & (N_BUCKETS - 1)) : b;
     pending = pending && !done && !give_up;  // a lost compare-and-swap looks at the same bucket again
+  }
+  return !__any(fail);
+}
+
+// The table inserts of the mesh path as a STREAM: a lane that has finished its run takes the next one from
+// the wave's queue at once, and a lane that has not (lost a compare-and-swap, met a full bucket) keeps its
+// run for the next trip -- also across the 64-row blocks of a rows round (`carry`).  wave_insert() above
+// loops until the slowest of its 64 lanes is done: 1.75 trips per 64 runs on the headline workload with most
+// lanes idle in the later ones, each trip a 1 KiB bucket read of the whole wave; here it is 1.33, every trip
+// but the last few of a round on (nearly) 64 runs.  (Tried and slower: linear probing with one returning
+// compare-and-swap per probe instead of the bucket read -- 2.3 trips per 64 runs, +12 % kernel time.)
+struct InsertCarry {  // per lane
+  uint32_t want, q;
+  uint32_t b;         // bits 0..15 bucket, 16.. probes so far
+  bool have;
+};
+
+__device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __restrict__ queue, int n_q, bool drain,
+                                              InsertCarry& c, unsigned int& claimed, unsigned int& trips) {
+  int next = 0;  // wave uniform: first queue item nobody has taken yet
+  bool fail = false;
+  for (;;) {
+    const unsigned long long idle_m = __ballot(!c.have);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+    const bool fresh = next < n_q;  // this trip starts new runs
+    if (!c.have && next + rank < n_q) {
+      const uint2 item = queue[next + rank];
+      c.want = item.x;
+      c.q = item.y;
+      c.b = hash_bucket(item.x & KEY_MASK);
+      c.have = true;
+    }
+    next = min(n_q, next + (int)__popcll(idle_m));
+    if (!__any(c.have)) break;
+    if (!fresh && !drain) break;  // queue used up: the unfinished runs ride along with the next block's
+    trips++;  // diagnostic builds only (dead code otherwise)
+    const uint32_t key = c.want & KEY_MASK;
+    const uint32_t b = c.b & 0xffffu;
+    const uint4 k4 = *reinterpret_cast<const uint4*>(&sh.keys[b * BUCKET]);
+    const bool m0 = (k4.x & KEY_MASK) == key, m1 = (k4.y & KEY_MASK) == key;
+    const bool m2 = (k4.z & KEY_MASK) == key, m3 = (k4.w & KEY_MASK) == key;
+    const bool e0 = k4.x == EMPTY, e1 = k4.y == EMPTY, e2 = k4.z == EMPTY, e3 = k4.w == EMPTY;
+    const bool any_m = m0 || m1 || m2 || m3, any_e = e0 || e1 || e2 || e3;
+    const uint32_t pos_m = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : 3u));
+    const uint32_t pos_e = e0 ? 0u : (e1 ? 1u : (e2 ? 2u : 3u));
+    const uint32_t h = b * BUCKET + (any_m ? pos_m : pos_e);
+    uint32_t cur = m0 ? k4.x : (m1 ? k4.y : (m2 ? k4.z : k4.w));
+    const bool try_claim = c.have && !any_m && any_e;
+    uint32_t old = 0u;
+    if (try_claim) old = atomicCAS(&sh.keys[h], EMPTY, c.want);
+    const bool won = try_claim && old == EMPTY;
+    const bool same = try_claim && (old & KEY_MASK) == key;  // another lane claimed it for this key
+    cur = won ? c.want : (same ? old : cur);
+    const bool done = c.have && (any_m || won || same);
+    if (done) {
+      if (cur < c.want) atomicMax(&sh.keys[h], c.want);
+      atomicAdd(&sh.chg[h], (unsigned long long)c.q);
+    }
+    claimed += (unsigned int)__popcll(__ballot(won));
+    const bool advance = c.have && !any_m && !any_e;  // full bucket of other keys
+    const uint32_t probes = (c.b >> 16) + (advance ? 1u : 0u);
+    const bool give_up = advance && probes >= (uint32_t)MAX_BUCKET_PROBES;
+    fail = fail || give_up;
+    c.b = (advance ? ((b + 1u) & (uint32_t)(N_BUCKETS - 1)) : b) | (probes << 16);
+    c.have = c.have && !done && !give_up;  // a lost compare-and-swap looks at the same bucket again
   }
   return !__any(fail);
 }
@@ -530,7 +597,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
           const int wave = tid >> 6;
           const McEntry* __restrict__ entries = reinterpret_cast<const McEntry*>(&sh.st_ix[0][0]);
           const double lo_mm = (double)lut_lo, hi_mm = (double)(lut_lo + lut_n);
-          unsigned int claimed = 0u;
+          unsigned int claimed = 0u, diag_trips = 0u;
           bool ok = true;
           for (int st = wave; st < n_stage && ok; st += N_WAVES) {  // wave uniform
             const McEntry m = entries[st];
@@ -551,7 +618,7 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
               const int ixx = (fx >= lo_mm && fx < hi_mm) ? (int)fx - lut_lo : lut_n;
               const int iyy = (fy >= lo_mm && fy < hi_mm) ? (int)fy - lut_lo : lut_n;
               const int pad = (int)lut[ixx * (lut_n + 1) + iyy];  // -1 off the plane / beam pad
-              ok = wave_insert(sh, word_hi | (uint32_t)max(pad, 0), q, k < m.n_prim && pad >= 0, claimed);
+              ok = wave_insert(sh, word_hi | (uint32_t)max(pad, 0), q, k < m.n_prim && pad >= 0, claimed, diag_trips);
             }
           }
           if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);
@@ -569,7 +636,14 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
           // sample read neighbouring addresses.
           const unsigned int row_pitch = 2u * (unsigned int)(lut_n + 1);  // bytes per iy row
           unsigned int claimed = 0u;  // new keys of this wave (wave uniform)
+          unsigned int diag_trips = 0u, diag_calls = 0u;
+          InsertCarry carry;
+          carry.want = 0u; carry.q = 0u; carry.b = 0u; carry.have = false;
           bool ok = true;
+#ifdef ATTPC_SC_SKEW  // experiment: start half of the waves late, so that their LDS-bound insert phases meet the
+                      // VALU-bound row phases of the others
+          if (wave >= N_WAVES / 2) __builtin_amdgcn_s_sleep(ATTPC_SC_SKEW);
+#endif
           for (int row0 = wave * 64; row0 < n_rows; row0 += SC_THREADS) {  // wave-uniform trip count
             const int row = min(row0 + lane, n_rows - 1);
             const bool have = row0 + lane < n_rows;
@@ -674,10 +748,10 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
               PHASE_SYNC;
               PHASE_MARK(10);
 #endif
-              for (int k0 = 0; k0 < n_q && ok; k0 += 64) {  // wave uniform
-                const uint2 item = queue[min(k0 + lane, n_q - 1)];
-                ok = wave_insert(sh, item.x, item.y, k0 + lane < n_q, claimed);
-              }
+#ifndef ATTPC_ABL_NOINSERT  // (ablation builds only: how long does the kernel take without the table inserts)
+              ok = stream_insert(sh, queue, n_q, false, carry, claimed, diag_trips);
+#endif
+              diag_calls += (unsigned int)(n_q + 63) / 64u;
 #ifdef ATTPC_PHASE_TIMERS
               PHASE_SYNC;
               PHASE_MARK(11);
@@ -687,7 +761,9 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
             ok = ok && !__any(!slow_ok);  // the slow path fails in single lanes
             if (!ok) break;    // table too full: the whole wave stops together
           }
+          if (ok) ok = stream_insert(sh, queue, 0, true, carry, claimed, diag_trips);  // the runs still under way
           if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);  // rows of the window's flush
+          PHASE_COUNT(5, (unsigned long long)diag_trips + ((unsigned long long)diag_calls << 32));
           return ok;
         };
 

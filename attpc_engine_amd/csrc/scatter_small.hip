@@ -6,7 +6,7 @@
 #ifndef ATTPC_SC_THREADS
 #define ATTPC_SC_THREADS 512
 #define ATTPC_SC_HASH_BITS 12
-#define ATTPC_SC_STAGE 112
+#define ATTPC_SC_STAGE 102  // two whole row passes (2 x 512 rows = 16 blocks of 64: two per wave)
 #define ATTPC_SC_WG_PER_CU 2
 #endif
 #include "scatter.hip"

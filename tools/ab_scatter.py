@@ -19,6 +19,8 @@ def child(workloads_csv: str, n: int) -> None:
     from attpc_engine_amd.engine import Engine
 
     ctx = _abi.Context(0)
+    if os.environ.get("ATTPC_AB_VARIANT"):  # 1 = small, 2 = big scatter build
+        ctx.set_option("scatter_variant", int(os.environ["ATTPC_AB_VARIANT"]))
     out = {}
     for name in workloads_csv.split(","):
         pipe, cfg, idx = workloads.WORKLOADS[name]()

@@ -718,7 +718,9 @@ int32_t run_batch_chunks(attpc_ctx* ctx, const attpc_event_layout& lay, const Tr
   };
   while (e0 < nb) {
     const bool pilot = ctx->rows_per_event <= 0.0;  // only ever true with nothing in flight
-    const uint32_t n = next_chunk_events(ctx, nb - e0);
+    // delivered clouds are PCIe bound: small chunks, so that the copy of one hides the scatter and
+    // assembly of the next from the first chunk on
+    const uint32_t n = std::min<uint32_t>(next_chunk_events(ctx, nb - e0), 16384u);
     const Chunk c{e0, n, seq % MAX_SLOTS};
     const int set = seq & 1;
     // an overflow of the chunk in flight is repaired inside complete(); queue this one behind it

@@ -11,7 +11,7 @@
 // binary search; sum order differs from the reference's sequential loop, i.e. last-bit differences.
 //
 // One workgroup per event; the kept rows are written in ascending z (the z-sort of writer.py:236-238 on
-// the device: counting sort over the integer time bucket + rank inside the bucket).
+// the device: counting sort over time bucket x sixteenths of the jitter + rank inside the bin).
 // Bound: HBM (32 B read per cloud row, twice; 72 B written per kept row).
 #include "tracks_args.hpp"
 
@@ -51,11 +51,18 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_count_kernel(SpyralDev sp, 
 }
 
 // Kept rows of one event, converted and written in ascending z (writer.py:232-238: threshold, then
-// argsort of column 2).  z falls with the time bucket, and the integer time bucket is a 9-bit key, so the
-// sort is a counting sort over the 512 buckets (highest bucket first) followed by a rank inside each
-// bucket on the jittered time bucket itself (larger first; equal values keep their cloud order -- the
-// reference's argsort is unstable, so ties have no defined order there).  The bucket-grouped
-// (row, time bucket) list lives in a global scratch range of the event's own cloud rows.
+// argsort of column 2).  z falls with the time bucket, so the sort key is the jittered time bucket,
+// descending.  Counting sort over SORT_BINS = 512 time buckets x 16 sixteenths of the jitter (highest
+// first; the bin index is a monotone function of the key), then a rank inside each bin on the key itself
+// (larger first; equal keys keep their cloud order -- the reference's argsort is unstable, so ties have no
+// defined order there).  Bins hold a few rows each, so the rank costs a handful of comparisons per row
+// whatever the event looks like (512 bins alone left hundreds of rows per bin for tracks across the
+// drift direction, and a quadratic rank).  The bin-grouped (row, key) list lives in a global scratch
+// range of the event's own cloud rows.
+constexpr int SORT_SUB = 16;
+constexpr int SORT_BINS = ATTPC_NUM_TB * SORT_SUB;           // 8192
+constexpr int SORT_BINS_PER_THREAD = SORT_BINS / SP_THREADS;  // 32
+
 __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, const int64_t* __restrict__ event_start,
                                                                    const int64_t* __restrict__ kept_start,
                                                                    const double* __restrict__ points,
@@ -64,9 +71,8 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, 
                                                                    int64_t* __restrict__ out_labels,
                                                                    uint32_t* __restrict__ sort_idx,
                                                                    double* __restrict__ sort_key) {
-  __shared__ uint32_t bin_count[ATTPC_NUM_TB];
-  __shared__ uint32_t bin_start[ATTPC_NUM_TB + 1];
-  __shared__ uint32_t bin_cursor[ATTPC_NUM_TB];
+  __shared__ uint32_t bin_cursor[SORT_BINS];     // counts, then the next free position of every bin
+  __shared__ uint32_t bin_start[SORT_BINS + 1];
   __shared__ uint32_t wave_total[SP_THREADS / 64];
   const uint32_t e = blockIdx.x;
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -74,33 +80,39 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, 
   const int64_t out0 = kept_start[e];
   const uint32_t n_kept = (uint32_t)(kept_start[e + 1] - out0);
   if (n_kept == 0u) return;  // uniform
-  for (int b = t; b < ATTPC_NUM_TB; b += SP_THREADS) bin_count[b] = 0u;
+  for (int b = t; b < SORT_BINS; b += SP_THREADS) bin_cursor[b] = 0u;
   block_sync();
-  auto bin_of = [](double tb) -> int {  // ascending z = descending time bucket
-    int b = (int)tb;
-    b = b < 0 ? 0 : (b > ATTPC_NUM_TB - 1 ? ATTPC_NUM_TB - 1 : b);
-    return ATTPC_NUM_TB - 1 - b;
+  auto bin_of = [](double tb) -> int {  // ascending z = descending time bucket; monotone in tb
+    double c = tb < 0.0 ? 0.0 : tb;
+    int whole = (int)c;
+    whole = whole > ATTPC_NUM_TB - 1 ? ATTPC_NUM_TB - 1 : whole;
+    int sub = (int)((c - (double)whole) * (double)SORT_SUB);  // exact: a power-of-two scale
+    sub = sub > SORT_SUB - 1 ? SORT_SUB - 1 : sub;
+    return (ATTPC_NUM_TB - 1 - whole) * SORT_SUB + (SORT_SUB - 1 - sub);
   };
   for (int64_t r = lo + t; r < hi; r += SP_THREADS)
-    if (amplitude(sp, points[3 * r + 2]) > sp.threshold) atomicAdd(&bin_count[bin_of(points[3 * r + 1])], 1u);
+    if (amplitude(sp, points[3 * r + 2]) > sp.threshold) atomicAdd(&bin_cursor[bin_of(points[3 * r + 1])], 1u);
   block_sync();
-  {  // exclusive prefix over the 512 buckets: two per thread, wave scan, wave offsets
-    static_assert(ATTPC_NUM_TB == 2 * SP_THREADS, "two buckets per thread");
-    const uint32_t c0 = bin_count[2 * t], c1 = bin_count[2 * t + 1];
-    uint32_t incl = c0 + c1;
+  {  // exclusive prefix over the bins: 32 consecutive bins per thread, wave scan, wave offsets
+    uint32_t local = 0u;
+    for (int k = 0; k < SORT_BINS_PER_THREAD; ++k) local += bin_cursor[t * SORT_BINS_PER_THREAD + k];
+    uint32_t incl = local;
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t up = __shfl_up(incl, off);
       incl += lane >= off ? up : 0u;
     }
     if (lane == 63) wave_total[wave] = incl;
     block_sync();
-    uint32_t excl = incl - (c0 + c1);
-    for (int w = 0; w < wave; ++w) excl += wave_total[w];
-    bin_start[2 * t] = excl;
-    bin_start[2 * t + 1] = excl + c0;
-    bin_cursor[2 * t] = excl;
-    bin_cursor[2 * t + 1] = excl + c0;
-    if (t == SP_THREADS - 1) bin_start[ATTPC_NUM_TB] = excl + c0 + c1;
+    uint32_t run = incl - local;
+    for (int w = 0; w < wave; ++w) run += wave_total[w];
+    for (int k = 0; k < SORT_BINS_PER_THREAD; ++k) {
+      const int b = t * SORT_BINS_PER_THREAD + k;
+      const uint32_t c = bin_cursor[b];
+      bin_start[b] = run;
+      bin_cursor[b] = run;
+      run += c;
+    }
+    if (t == SP_THREADS - 1) bin_start[SORT_BINS] = run;
   }
   block_sync();
   for (int64_t r = lo + t; r < hi; r += SP_THREADS) {
@@ -111,7 +123,9 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, 
       sort_key[lo + p] = tb;
     }
   }
-  __threadfence();
+  // workgroup scope is enough (the list is written and read by this workgroup only) -- an agent-scope fence
+  // here writes back the whole L2 once per event, with gigabytes of dirty cloud rows in it
+  __threadfence_block();
   block_sync();
   for (uint32_t p = (uint32_t)t; p < n_kept; p += SP_THREADS) {
     const uint32_t ri = sort_idx[lo + p];

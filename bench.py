@@ -31,6 +31,12 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+CLOCK_HZ = 2.4e9       # peak engine clock (same guide); 256 CUs x 4 SIMDs, a wave64 VALU instruction issues over 4 cycles
+N_CUS, SIMDS_PER_CU = 256, 4
+# LDS atomics: an LDS instruction of a wave64 is serviced 32 lanes per LDS cycle at best (two lane groups,
+# MI355X_MICROARCH.md "LDS"), one LDS pipeline per CU -> at most CLOCK / 2 wave-level atomics per CU and second
+LDS_ATOMIC_PEAK_PER_S = N_CUS * CLOCK_HZ / 2.0
+PMC_PROFILE = "r02_pmc.json"
 
 
 def main() -> None:
@@ -43,6 +49,8 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--chunk-events", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-delivered", action="store_true", help="skip the delivered-to-host leg (clouds over PCIe)")
+    ap.add_argument("--delivered-events", type=int, default=50_000)
     args = ap.parse_args()
 
     from attpc_engine_amd import _abi, sharding, workloads
@@ -111,6 +119,7 @@ def main() -> None:
     avg_ms = agg[ms_key] / launches
     achieved = events_per_launch * bytes_per_event / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic, traffic_note = measured_traffic(args.workload, dominant, events_per_launch)
+    issue = issue_roofs(args.workload, dominant, events_per_launch, avg_ms)
     line = {
         "metric": "events/sec (whole node); kinematics + full detector batch, point clouds device-resident (no D2H)",
         "value": value,
@@ -155,26 +164,95 @@ def main() -> None:
             "avg_launch_ms": avg_ms,
             "events_per_launch": events_per_launch,
             "kernel_ms_total": {k: agg[v[0]] for k, v in kernels.items()} | {"kin_run_kernel": agg["ms_kinematics"]},
-            "note": "path is f64-VALU / LDS-atomic bound, not HBM bound (DESIGN.md); frac is vs the HBM roof",
+            "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md 4.3): frac is vs the HBM roof as the "
+                    "contract asks, valu_issue_frac is the roof that binds",
+            **issue,
         },
     }
+    if world_size == 1 and not args.no_delivered and config is not None:
+        try:
+            line["delivered"] = delivered(engine, min(args.delivered_events, args.events), args.seed, bytes_per_event, p_event)
+        except Exception as exc:  # the headline line must not depend on this leg
+            line["delivered"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world_size == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
     print(json.dumps(line), flush=True)
 
 
-def measured_traffic(workload: str, kernel: str, events_per_launch: float):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE +
-    WRITE_SIZE, KiB -> bytes; see profiles/r01_hbm_traffic.json for the correction notes),
-    scaled from the profiled launch size to this run's.  None when no profile exists."""
-    path = ROOT / "profiles" / "r01_hbm_traffic.json"
+def _pmc(workload: str, kernel: str):
+    """Counter totals of `kernel` and the events of the profiled run from the committed rocprofv3 PMC passes
+    (profiles/r02_pmc.json, written by tools/pmc_profile.sh), or None."""
     try:
-        prof = json.loads(path.read_text())[workload]
-        k = prof[kernel]
-        per_event = (k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0 / prof["events_per_launch"]
-        return per_event * events_per_launch, f"profiles/{path.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH uncorrected)"
+        prof = json.loads((ROOT / "profiles" / PMC_PROFILE).read_text())[workload]
+        return prof[kernel], float(prof["events"])
     except (OSError, KeyError, ValueError):
+        return None
+
+
+def measured_traffic(workload: str, kernel: str, events_per_launch: float):
+    """HBM bytes per launch of `kernel`: FETCH_SIZE + WRITE_SIZE (KiB -> bytes) of the committed PMC passes,
+    per event, times this run's events per launch.  WRITE_SIZE equals the algorithmic output bytes to 0.1 %;
+    FETCH_SIZE is quoted uncorrected: the guide's x2 correction is for wide (16 B / lane) streaming reads,
+    this kernel reads 32-byte sample records and 2-byte LUT gathers.  None when no profile exists."""
+    got = _pmc(workload, kernel)
+    if got is None or "FETCH_SIZE" not in got[0] or "WRITE_SIZE" not in got[0]:
         return None, "no PMC profile for this workload"
+    counters, events = got
+    per_event = (counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0 / events
+    return per_event * events_per_launch, f"profiles/{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in passes of their own, FETCH uncorrected)"
+
+
+def issue_roofs(workload: str, kernel: str, events_per_launch: float, avg_launch_ms: float) -> dict:
+    """The roofs that do bind: VALU issue and LDS atomics.  Instruction counts per event from the committed PMC
+    pass, time from THIS run's launches (HIP events)."""
+    got = _pmc(workload, kernel)
+    if got is None or avg_launch_ms <= 0:
+        return {"valu_issue_frac": None, "lds_atomics_per_s": None}
+    counters, events = got
+    seconds = avg_launch_ms * 1e-3
+    out = {}
+    if "SQ_INSTS_VALU" in counters:
+        valu = counters["SQ_INSTS_VALU"] / events * events_per_launch
+        out["valu_insts_per_event"] = counters["SQ_INSTS_VALU"] / events
+        # wave64 VALU instruction = 4 issue cycles of one SIMD (16 lanes per cycle; f64 ones take longer, so
+        # this is a lower bound of the busy share)
+        out["valu_issue_frac"] = valu * 4.0 / (N_CUS * SIMDS_PER_CU * CLOCK_HZ * seconds)
+    if "SQ_ACTIVE_INST_VALU" in counters and "SQ_BUSY_CYCLES" in counters and counters["SQ_BUSY_CYCLES"] > 0:
+        out["valu_busy_frac_profiled"] = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / (counters["SQ_BUSY_CYCLES"] * SIMDS_PER_CU) \
+            if counters["SQ_BUSY_CYCLES"] else None
+    if "SQ_INSTS_LDS_ATOMIC" in counters:
+        atomics = counters["SQ_INSTS_LDS_ATOMIC"] / events * events_per_launch
+        out["lds_atomics_per_event"] = counters["SQ_INSTS_LDS_ATOMIC"] / events
+        out["lds_atomics_per_s"] = atomics / seconds
+        out["lds_atomics_peak_per_s"] = LDS_ATOMIC_PEAK_PER_S
+        out["lds_atomics_frac"] = atomics / seconds / LDS_ATOMIC_PEAK_PER_S
+        out["lds_atomics_unit"] = "wave-level LDS atomic instructions (ds_cmpst / ds_max / ds_add_u64) per second, whole chip"
+    out["issue_source"] = f"profiles/{PMC_PROFILE} (instruction counts per event) x this run's launch time"
+    return out
+
+
+def delivered(engine, n: int, seed: int, bytes_per_event: float, p_event: float) -> dict:
+    """Delivered-to-host throughput: the same events with their clouds copied into pinned host
+    arrays (reference dtypes, CSR) and, second, with the GET response / ADC threshold / Spyral rows / z-sort
+    done on the device and only those rows copied.  One untimed pass sizes and pins the buffers."""
+    out = {"events": n, "host_buffers": "page-locked (attpc_host_alloc), reused across calls"}
+    cap = int(p_event * 1.25) + 64
+    for name, run in (("cloud", lambda first: engine.run(n, seed=seed, first_event=first, fetch=True, pinned=True,
+                                                         reuse_buffers=True, capacity_per_event=cap)),
+                      ("spyral_rows", lambda first: engine.run_spyral(n, seed=seed, first_event=first, pinned=True,
+                                                                      reuse_buffers=True, capacity_per_event=cap))):
+        run(10_000_000)  # untimed: allocates and pins the host arrays (seconds for tens of GB)
+        t0 = time.perf_counter()
+        res = run(20_000_000)
+        dt = time.perf_counter() - t0
+        rows = int(res["offsets"][-1])
+        del res                    # un-pinning the arrays takes a second as well: outside every timed region
+        engine._out_cache = None
+        width = 3 if name == "cloud" else 8
+        copied = rows * (width + 1) * 8 + (n + 1) * 8
+        out[name] = {"events_per_s": n / dt, "rows_per_event": rows / n, "bytes_per_event": copied / n,
+                     "pcie_GBps": copied / dt / 1e9}
+    return out
 
 
 def cpu_baseline(workload: str, seed: int) -> dict:

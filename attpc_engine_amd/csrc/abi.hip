@@ -84,7 +84,7 @@ struct attpc_ctx {
 
   TrackSet tset[2];
   // cloud of one chunk
-  DevBuf points, labels, segments, ev_rows, lone_list, out_ctrl;
+  DevBuf points, labels, segments, ev_rows, lone_list, lone_chg, lone_mask, out_ctrl;
   unsigned long long* h_out_ctrl = nullptr;  // pinned [MAX_SLOTS][CTRL_WORDS]
   hipEvent_t s0[MAX_SLOTS] = {}, s1[MAX_SLOTS] = {};
   int64_t cloud_capacity = 0, seg_capacity = 0;
@@ -176,17 +176,23 @@ struct ChunkResult {
 };
 
 // ------------------------------------------------------------------ small device helpers ----
-// out[i] = sum of in[0..i), i = 0..n (one workgroup; n is a chunk's event count), *total = out[n]
+// out[i] = sum of in[0..i), i = 0..n (one workgroup; n is a chunk's event count), *total = out[n].
+// `ctrl` (may be null): control words of the scatter launch that produced the counts -- if that launch ran
+// out of cloud or segment capacity (ctrl[6]) its rows were not all written and its segment list has
+// unwritten slots, so every offset becomes 0: the kernels behind this one then see empty events and touch
+// nothing, and the host repeats the launch with larger buffers.
 __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint32_t* __restrict__ in, uint32_t n,
-                                                              int64_t* __restrict__ out, int64_t* __restrict__ total) {
+                                                              int64_t* __restrict__ out, int64_t* __restrict__ total,
+                                                              const unsigned long long* __restrict__ ctrl) {
   __shared__ long long wave_sum[16];
   __shared__ long long carry;
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool dead = ctrl != nullptr && ctrl[6] != 0ull;
   if (t == 0) carry = 0;
   block_sync();
   for (uint32_t base = 0; base < n; base += 1024u) {
     const uint32_t i = base + (uint32_t)t;
-    const long long v = i < n ? (long long)in[i] : 0ll;
+    const long long v = (i < n && !dead) ? (long long)in[i] : 0ll;
     long long incl = v;
     for (int off = 1; off < 64; off <<= 1) {
       const long long up = __shfl_up(incl, off);
@@ -218,6 +224,7 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const Segment* __r
                                                               const int64_t* __restrict__ labels,
                                                               double* __restrict__ out_points,
                                                               int64_t* __restrict__ out_labels) {
+  if (ctrl[6] != 0ull) return;  // the launch ran out of capacity: unwritten segment slots, see exclusive_scan_kernel
   const unsigned long long n_all = ctrl[1];
   const uint32_t n_segs = (uint32_t)(n_all < (unsigned long long)seg_capacity ? n_all : (unsigned long long)seg_capacity);
   for (uint32_t s = blockIdx.x; s < n_segs; s += gridDim.x) {
@@ -424,6 +431,9 @@ int32_t enqueue_scatter(attpc_ctx* ctx, int slot, const attpc_event_layout& lay,
     if ((rc = ensure(ctx, ctx->ev_rows, (size_t)std::max<uint32_t>(n, (uint32_t)std::max(1, ctx->chunk_events)) * sizeof(uint32_t)))) return rc;
     ctx->cloud_capacity = want_rows;
     ctx->seg_capacity = want_segs;
+    // test hook: poison the segment list, so that a consumer of slots a launch did not write (one that ran
+    // out of capacity) cannot go unnoticed on freshly allocated, zero-filled memory
+    if (ctx->opt_tiny) HIP_TRY(ctx, hipMemsetAsync(ctx->segments.p, 0x7f, ctx->segments.bytes, ctx->stream));
   }
   unsigned long long* d_ctrl = static_cast<unsigned long long*>(ctx->out_ctrl.p) + (size_t)slot * CTRL_WORDS;
   HIP_TRY(ctx, hipMemsetAsync(d_ctrl, 0, CTRL_WORDS * sizeof(unsigned long long), ctx->stream));
@@ -438,6 +448,8 @@ int32_t enqueue_scatter(attpc_ctx* ctx, int slot, const attpc_event_layout& lay,
   sa.out.ev_rows = static_cast<uint32_t*>(ctx->ev_rows.p);
   sa.out.lone_list = static_cast<LoneBucket*>(ctx->lone_list.p);
   sa.out.lone_capacity = LONE_CAPACITY;
+  sa.out.lone_chg = static_cast<unsigned long long*>(ctx->lone_chg.p);
+  sa.out.lone_mask = static_cast<uint32_t*>(ctx->lone_mask.p);
   sa.out.capacity = ctx->cloud_capacity;
   sa.out.seg_capacity = ctx->seg_capacity;
   sa.seed = seed;
@@ -451,7 +463,7 @@ int32_t enqueue_scatter(attpc_ctx* ctx, int slot, const attpc_event_layout& lay,
   else launch_scatter_kernel_big(p.wgs, ctx->stream, sa);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->s1[slot], ctx->stream));
-  launch_lone_bucket_kernel(std::min<uint32_t>(64u, (uint32_t)ctx->n_cus), ctx->stream, sa);  // exits at once without lone buckets
+  launch_lone_bucket_kernel((uint32_t)LONE_WORKGROUPS, ctx->stream, sa);  // exits at once without lone buckets
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out_ctrl + (size_t)slot * CTRL_WORDS, d_ctrl, CTRL_WORDS * sizeof(unsigned long long),
                               hipMemcpyDeviceToHost, ctx->stream));
@@ -540,7 +552,7 @@ int32_t enqueue_assembly(attpc_ctx* ctx, int slot, AsmSet& as, uint32_t n, bool 
   if ((rc = ensure_pinned_start(ctx, as, (size_t)n + 1))) return rc;
   const unsigned long long* d_ctrl = static_cast<const unsigned long long*>(ctx->out_ctrl.p) + (size_t)slot * CTRL_WORDS;
   hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const uint32_t*>(ctx->ev_rows.p), n,
-                     static_cast<int64_t*>(as.ev_start.p), static_cast<int64_t*>(nullptr));
+                     static_cast<int64_t*>(as.ev_start.p), static_cast<int64_t*>(nullptr), d_ctrl);
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(gather_segments_kernel, dim3(4096), dim3(256), 0, ctx->stream, static_cast<const Segment*>(ctx->segments.p),
                      d_ctrl, ctx->seg_capacity, static_cast<const int64_t*>(as.ev_start.p),
@@ -561,7 +573,8 @@ int32_t enqueue_assembly(attpc_ctx* ctx, int slot, AsmSet& as, uint32_t n, bool 
                         static_cast<const double*>(as.points.p), static_cast<uint32_t*>(as.kept.p));
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const uint32_t*>(as.kept.p), n,
-                       static_cast<int64_t*>(as.kept_start.p), static_cast<int64_t*>(nullptr));
+                       static_cast<int64_t*>(as.kept_start.p), static_cast<int64_t*>(nullptr),
+                       static_cast<const unsigned long long*>(nullptr));
     HIP_TRY(ctx, hipGetLastError());
     launch_spyral_write(ctx->stream, ctx->spyral, n, static_cast<const int64_t*>(as.ev_start.p),
                         static_cast<const int64_t*>(as.kept_start.p), static_cast<const double*>(as.points.p),
@@ -663,6 +676,12 @@ int32_t run_batch_chunks(attpc_ctx* ctx, const attpc_event_layout& lay, const Tr
   }
   if ((rc = ensure(ctx, ctx->out_ctrl, (size_t)MAX_SLOTS * CTRL_WORDS * sizeof(unsigned long long)))) return rc;
   if ((rc = ensure(ctx, ctx->lone_list, (size_t)LONE_CAPACITY * sizeof(LoneBucket)))) return rc;
+  if (!ctx->lone_chg.p) {  // lone_bucket_kernel's tables: zero once, the kernel leaves them zero
+    if ((rc = ensure(ctx, ctx->lone_chg, (size_t)LONE_WORKGROUPS * LONE_PADS * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(ctx, ctx->lone_mask, (size_t)LONE_WORKGROUPS * (LONE_PADS / 4) * sizeof(uint32_t)))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->lone_chg.p, 0, ctx->lone_chg.bytes, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->lone_mask.p, 0, ctx->lone_mask.bytes, ctx->stream));
+  }
   struct Chunk { uint32_t e0, n; int slot; };
   if (!out) {
     // device resident: queue up to MAX_SLOTS chunks back to back, read their control words once
@@ -861,7 +880,8 @@ int32_t attpc_ctx_destroy(attpc_ctx* ctx) {
   free_all(ctx->kin_allocs);
   free_all(ctx->det_allocs);
   free_all(ctx->spyral_allocs);
-  std::vector<DevBuf*> bufs = {&ctx->points, &ctx->labels, &ctx->segments, &ctx->ev_rows, &ctx->lone_list, &ctx->out_ctrl,
+  std::vector<DevBuf*> bufs = {&ctx->points, &ctx->labels, &ctx->segments, &ctx->ev_rows, &ctx->lone_list, &ctx->lone_chg,
+                               &ctx->lone_mask, &ctx->out_ctrl,
                                &ctx->sort_idx, &ctx->sort_key};
   for (TrackSet& ts : ctx->tset) {
     for (DevBuf* b : {&ts.p4, &ts.vertex, &ts.status, &ts.attempts, &ts.arena, &ts.block_table, &ts.counts, &ts.n_steps, &ts.ctrl})

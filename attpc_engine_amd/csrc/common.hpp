@@ -152,6 +152,7 @@ struct Segment {          // one flushed window of one event
 // one bucket the key is the pad, so that kernel's table is direct mapped over the 14-bit pad range of the
 // key -- no hashing and no capacity limit (the reference's dict has none, simulator.py:93-101).
 constexpr int LONE_PADS = 1 << 14;
+constexpr int LONE_WORKGROUPS = 32;
 struct LoneBucket {
   uint32_t event;   // launch-local event
   uint32_t tb;      // time bucket
@@ -167,6 +168,8 @@ struct CloudBuffers {
   uint32_t* ev_rows;         // [n_events] cloud rows of every event of the launch
   LoneBucket* lone_list;     // [lone_capacity] time buckets left to lone_bucket_kernel, count in ctrl[29]
   uint32_t lone_capacity;
+  unsigned long long* lone_chg;  // [LONE_WORKGROUPS][LONE_PADS]      lone_bucket_kernel's tables, all 0 between uses
+  uint32_t* lone_mask;           // [LONE_WORKGROUPS][LONE_PADS / 4]
   int64_t capacity;
   int64_t seg_capacity;
 };

@@ -8,24 +8,25 @@
 // the normal case).
 //
 // Inside one time bucket the key is the pad, so the dictionary is a direct-mapped array over the
-// 14-bit pad range of the key: u64 electrons[16384] (128 KiB of LDS) plus an 8-bit mask of the touching
-// nuclei per pad (16 KiB), "label = last nucleus in `indices` order that touched the key"
-// (transporter.py:249) being the highest set bit.  One workgroup per recorded bucket: every thread takes
-// whole entries (sample x slice) of the bucket and walks their 100 mesh pixels (transporter.py:172-249)
-// -- or, with the Monte-Carlo diffusion extension, their electrons -- with LDS atomics; then the lit pads
-// are appended to the launch's cloud as one more segment of the event, in the same row format and with
-// the same Philox time-bucket jitter as scatter_kernel's flush.  Simple rather than fast on purpose.
+// 14-bit pad range of the key: u64 electrons[16384] plus an 8-bit mask of the touching nuclei per pad,
+// "label = last nucleus in `indices` order that touched the key" (transporter.py:249) being the highest
+// set bit.  The arrays live in GLOBAL memory (one pair per workgroup, all-zero between uses): the kernel
+// is queued behind every scatter launch and must start at once beside whatever else is resident -- with
+// its table in LDS (144 KiB) each empty launch waited for a free compute unit, milliseconds of the
+// scatter stream per chunk.  One workgroup per recorded bucket: every thread takes whole entries
+// (sample x slice) of the bucket and walks their 100 mesh pixels (transporter.py:172-249) -- or, with the
+// Monte-Carlo diffusion extension, their electrons -- with (L2) atomics; then the lit pads are appended
+// to the launch's cloud as one more segment of the event, in the same row format and with the same Philox
+// time-bucket jitter as scatter_kernel's flush.  Simple rather than fast on purpose.
 #include "tracks_args.hpp"
 
 namespace attpc {
 
-constexpr int LONE_THREADS = 1024;
+constexpr int LONE_THREADS = 256;
 constexpr int LN_CTRL_LONE = 29;   // the same out.ctrl[] slots as scatter.hip
 constexpr int LN_CTRL_ROWS = 30;
 
 struct LoneShared {
-  unsigned long long chg[LONE_PADS];      // electrons per pad
-  uint32_t mask[LONE_PADS / 4];            // 8 bits per pad: bit k = touched by the nucleus at position k of `indices`
   double wtab[ATTPC_MESH_STEPS * ATTPC_MESH_STEPS];
   int blocks[ATTPC_MAX_SIM][MAX_BLOCKS_PER_TRACK];
   int cnt[ATTPC_MAX_SIM + 1];
@@ -50,8 +51,9 @@ __global__ __launch_bounds__(LONE_THREADS) void lone_bucket_kernel(ScatterArgs a
     const double di = (double)(p / MESH) - 4.5, dj = (double)(p % MESH) - 4.5;
     sh.wtab[p] = (36.0 / 81.0) / TWO_PI * exp(-(2.0 / 9.0) * (di * di + dj * dj));  // as in scatter.hip
   }
-  for (int i = t; i < LONE_PADS; i += LONE_THREADS) sh.chg[i] = 0ull;
-  for (int i = t; i < LONE_PADS / 4; i += LONE_THREADS) sh.mask[i] = 0u;
+  // electrons per pad / 8 bits per pad (bit k = touched by the nucleus at position k of `indices`)
+  unsigned long long* chg = a.out.lone_chg + (size_t)blockIdx.x * LONE_PADS;
+  uint32_t* mask = a.out.lone_mask + (size_t)blockIdx.x * (LONE_PADS / 4);
   if (t == 0) { sh.charge_sum = 0ull; sh.key_sum = 0ull; }
   block_sync();
 
@@ -61,8 +63,8 @@ __global__ __launch_bounds__(LONE_THREADS) void lone_bucket_kernel(ScatterArgs a
   };
   auto add = [&](int pad, unsigned long long q, int isim) {
     if (pad < 0 || pad >= LONE_PADS) return;
-    atomicOr(&sh.mask[pad >> 2], 1u << (8 * (pad & 3) + isim));
-    atomicAdd(&sh.chg[pad], q);
+    atomicOr(&mask[pad >> 2], 1u << (8 * (pad & 3) + isim));
+    atomicAdd(&chg[pad], q);
   };
 
   for (uint32_t rec = blockIdx.x; rec < n_lone; rec += gridDim.x) {
@@ -139,7 +141,8 @@ __global__ __launch_bounds__(LONE_THREADS) void lone_bucket_kernel(ScatterArgs a
     block_sync();
     // lit pads -> rows
     unsigned int mine = 0;
-    for (int pad = t; pad < LONE_PADS; pad += LONE_THREADS) mine += ((sh.mask[pad >> 2] >> (8 * (pad & 3))) & 0xffu) ? 1u : 0u;
+    for (int pad = t; pad < LONE_PADS; pad += LONE_THREADS)
+      mine += ((__hip_atomic_load(&mask[pad >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (8 * (pad & 3))) & 0xffu) ? 1u : 0u;
     if (mine) atomicAdd(&sh.n_lit, mine);
     block_sync();
     const unsigned int n_rows = sh.n_lit;
@@ -168,10 +171,10 @@ __global__ __launch_bounds__(LONE_THREADS) void lone_bucket_kernel(ScatterArgs a
     const unsigned long long base = sh.base;
     unsigned long long my_charge = 0ull, my_keys = 0ull;
     for (int pad = t; pad < LONE_PADS; pad += LONE_THREADS) {
-      const uint32_t m = (sh.mask[pad >> 2] >> (8 * (pad & 3))) & 0xffu;
+      const uint32_t m = (__hip_atomic_load(&mask[pad >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (8 * (pad & 3))) & 0xffu;
       if (m == 0u) continue;
-      const unsigned long long q = sh.chg[pad];
-      sh.chg[pad] = 0ull;
+      const unsigned long long q = __hip_atomic_load(&chg[pad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&chg[pad], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t key = ((uint32_t)tb << 14) | (uint32_t)pad;
       my_charge += q;
       my_keys += (event << 24) + (unsigned long long)key;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(LONE_THREADS) void lone_bucket_kernel(ScatterArgs a
     if (my_charge) atomicAdd(&sh.charge_sum, my_charge);
     if (my_keys) atomicAdd(&sh.key_sum, my_keys);
     block_sync();
-    for (int i = t; i < LONE_PADS / 4; i += LONE_THREADS) sh.mask[i] = 0u;
+    for (int i = t; i < LONE_PADS / 4; i += LONE_THREADS) __hip_atomic_store(&mask[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     block_sync();
   }
   if (t == 0) {

@@ -121,7 +121,7 @@ class RunStats(C.Structure):
         ("ms_kinematics", C.c_double), ("ms_tracks", C.c_double), ("ms_scatter", C.c_double),
         ("launches_kinematics", C.c_uint32), ("launches_tracks", C.c_uint32),
         ("launches_scatter", C.c_uint32), ("n_inconsistent", C.c_uint32),
-        ("n_lone_buckets", C.c_uint64),
+        ("n_lone_buckets", C.c_uint64), ("n_buffer_growths", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:

@@ -95,6 +95,7 @@ struct attpc_ctx {
   double segs_per_event = 0.0;
   double blocks_per_track = 0.0;   // observed arena blocks per track
   bool prefer_big = false;         // sticky: the small scatter variant met too many lone buckets
+  uint64_t n_growths = 0;          // device buffers (re)allocated so far (a steady workload stops growing)
 
   bool spyral_ready = false;
   SpyralDev spyral{};
@@ -126,6 +127,7 @@ int32_t fail(attpc_ctx* ctx, int32_t code, const char* fmt, ...) {
 // grow-only device buffer; the caller makes sure nothing in flight uses it when it has to grow
 int32_t ensure(attpc_ctx* ctx, DevBuf& b, size_t bytes) {
   if (bytes <= b.bytes) return ATTPC_OK;
+  ctx->n_growths++;
   if (b.p) HIP_TRY(ctx, hipFree(b.p));
   b.p = nullptr;
   b.bytes = 0;
@@ -283,8 +285,15 @@ int32_t launch_tracks(attpc_ctx* ctx, TrackSet& ts, const TrackLaunch& tl) {
     const uint32_t waves_needed = (n_tracks + 63) / 64;
     const uint32_t blocks = std::min<uint32_t>((waves_needed + 3) / 4, (uint32_t)ctx->n_cus * 8u);
     // every wave reserves arena blocks 64 at a time: that slack comes on top of what the samples need
-    const double per_track = ctx->blocks_per_track > 0.0 ? ctx->blocks_per_track * 1.15 + 0.25 : 3.0;
-    size_t want_blocks = std::max<size_t>(ts.arena_blocks, (size_t)((double)n_tracks * per_track) + (size_t)blocks * 4 * 64 + 1024);
+    // keep the arena while it covers the observed need with 3 % to spare, grow it by 25 % when it does not:
+    // the need per track moves by fractions of a percent from batch to batch, and re-allocating tens of GB
+    // for each such step costs more than the kernels (a too small arena is caught and the batch repeated)
+    const size_t pools = (size_t)blocks * 4 * 64 + 1024;
+    const double bpt = ctx->blocks_per_track;
+    const size_t need_blocks = bpt > 0.0 ? (size_t)((double)n_tracks * (bpt * 1.03 + 0.05)) + pools : (size_t)n_tracks * 3 + pools;
+    size_t want_blocks = ts.arena_blocks;
+    if (need_blocks > ts.arena_blocks)
+      want_blocks = bpt > 0.0 ? (size_t)((double)n_tracks * (bpt * 1.25 + 0.25)) + pools : need_blocks;
     if (ctx->opt_tiny && ts.arena_blocks == 0) want_blocks = 4;  // test hook: grow-and-rerun path
     if ((rc = ensure(ctx, ts.arena, want_blocks * ARENA_BLK * 4 * sizeof(double)))) return rc;
     ts.arena_blocks = want_blocks;
@@ -376,7 +385,8 @@ uint32_t next_chunk_events(const attpc_ctx* ctx, uint64_t remaining) {
 struct ScatterPlan {  // launch geometry of one chunk
   bool use_small = false;
   uint32_t wgs = 0, batch = 1, row_block = 1;
-  int64_t want_rows = 0, want_segs = 0;
+  int64_t need_rows = 0, need_segs = 0;  // the launch should fit in this much
+  int64_t grow_rows = 0, grow_segs = 0;  // what to allocate when the buffers are smaller than that
 };
 
 ScatterPlan plan_scatter(const attpc_ctx* ctx, uint32_t n) {
@@ -403,12 +413,18 @@ ScatterPlan plan_scatter(const attpc_ctx* ctx, uint32_t n) {
   const int64_t est_rows = (int64_t)((double)n * per_event) + 4096;
   p.row_block = est_rows / ((int64_t)p.wgs * 16) >= 16384 ? (uint32_t)std::min<int64_t>(est_rows / ((int64_t)p.wgs * 16), 1 << 18) : 1u;
   const int64_t hole_rows = p.row_block > 1u ? (int64_t)p.wgs * p.row_block + est_rows / 16 : 0;
-  p.want_rows = est_rows + hole_rows + 65536;
-  const double segs = ctx->segs_per_event > 0.0 ? ctx->segs_per_event * 1.25 + 1.0 : 6.0;
-  p.want_segs = (int64_t)((double)n * segs) + 4096 + (int64_t)p.wgs * 16;
+  // keep the buffers while they cover the estimate with 3 % to spare, grow them by 25 % when they do not:
+  // rows per event move by fractions of a percent from chunk to chunk, and re-allocating tens of GB for each
+  // such step costs more than the kernels (a too small buffer is caught and the launch repeated)
+  const double known = ctx->rows_per_event > 0.0 ? ctx->rows_per_event : 16384.0;
+  p.need_rows = (int64_t)((double)n * known * 1.03) + hole_rows + 65536;
+  p.grow_rows = (int64_t)((double)n * known * 1.25) + hole_rows + 65536;
+  const double segs = ctx->segs_per_event > 0.0 ? ctx->segs_per_event : 5.0;
+  p.need_segs = (int64_t)((double)n * (segs * 1.05 + 0.5)) + 4096 + (int64_t)p.wgs * 16;
+  p.grow_segs = (int64_t)((double)n * (segs * 1.5 + 1.0)) + 4096 + (int64_t)p.wgs * 16;
   if (ctx->opt_tiny && ctx->cloud_capacity == 0) {
-    p.want_rows = 64;  // test hook: start with buffers that are certainly too small
-    p.want_segs = 2;
+    p.need_rows = p.grow_rows = 64;  // test hook: start with buffers that are certainly too small
+    p.need_segs = p.grow_segs = 2;
   }
   return p;
 }
@@ -420,8 +436,9 @@ int32_t enqueue_scatter(attpc_ctx* ctx, int slot, const attpc_event_layout& lay,
                         uint64_t first_event, uint32_t e0, uint32_t n, int64_t min_rows, int64_t min_segs) {
   int32_t rc;
   const ScatterPlan p = plan_scatter(ctx, n);
-  const int64_t want_rows = std::max<int64_t>({ctx->cloud_capacity, p.want_rows, min_rows});
-  const int64_t want_segs = std::max<int64_t>({ctx->seg_capacity, p.want_segs, min_segs});
+  int64_t want_rows = ctx->cloud_capacity, want_segs = ctx->seg_capacity;
+  if (std::max(p.need_rows, min_rows) > ctx->cloud_capacity) want_rows = std::max(p.grow_rows, min_rows);
+  if (std::max(p.need_segs, min_segs) > ctx->seg_capacity) want_segs = std::max(p.grow_segs, min_segs);
   if (want_rows > ctx->cloud_capacity || want_segs > ctx->seg_capacity || (size_t)n * sizeof(uint32_t) > ctx->ev_rows.bytes) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may use the old buffers
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
@@ -765,6 +782,7 @@ int32_t run_events(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t
   int32_t rc;
   attpc_run_stats st{};
   st.n_events = n_events;
+  const uint64_t growths_before = ctx->n_growths;
   const int n_rows = lay.n_rows;
   int64_t row_cursor = 0;
   bool over = false;
@@ -813,6 +831,7 @@ int32_t run_events(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
   if (spyral) st.n_points = (uint64_t)row_cursor;  // rows that survive the threshold
+  st.n_buffer_growths = ctx->n_growths - growths_before;
   if (stats) *stats = st;
   if (over) return fail(ctx, ATTPC_E_CAPACITY, "cloud needs %lld rows, capacity %lld", (long long)row_cursor, (long long)out->capacity);
   if (st.n_failed || st.n_inconsistent)

@@ -1,6 +1,6 @@
 """Physical constants baked into the kernels (reference ``detector/constants.py:20-35``;
 the reference reads them from scipy's CODATA table -- the exact doubles are repeated in
-``csrc/attpc_hip.hip`` and checked against scipy in the CPU tests)."""
+``csrc/common.hpp`` and checked against scipy in the CPU tests)."""
 from scipy.constants import elementary_charge, physical_constants, speed_of_light
 
 NUM_TB: int = 512

@@ -84,7 +84,7 @@ def main() -> None:
     agg = {"ms_kinematics": 0.0, "ms_tracks": 0.0, "ms_scatter": 0.0, "launches_kinematics": 0,
            "launches_tracks": 0, "launches_scatter": 0}
     totals = {"n_points": 0, "n_track_samples": 0, "n_failed": 0, "n_sample_limit": 0, "n_lone_buckets": 0,
-              "n_inconsistent": 0}
+              "n_inconsistent": 0, "n_buffer_growths": 0}
     charge_acc = key_acc = 0
     for step in range(args.steps):
         stats = engine.run(n_events, seed=args.seed, first_event=step_first(step))["stats"]
@@ -145,6 +145,7 @@ def main() -> None:
             "algorithmic_bytes_per_event": bytes_per_event,
             "failed_events": failed,
             "lone_time_buckets": lone,
+            "buffer_growths_in_timed_steps": totals["n_buffer_growths"],
             "table_self_check_failures": totals["n_inconsistent"],
             "sample_limit_events": limit,
             "charge_checksum": str(charge_sum),  # u64 sums over all steps and ranks, as strings (beyond int64 / f64)

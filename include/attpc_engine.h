@@ -194,6 +194,7 @@ typedef struct attpc_run_stats {
                                  number of claimed keys; must be 0 */
   uint64_t n_lone_buckets;    /* time buckets that alone exceeded the LDS table and went through the
                                  direct-mapped table of lone_bucket_kernel (complete, just slower) */
+  uint64_t n_buffer_growths;  /* device buffers (re)allocated during this run; 0 once the sizes have settled */
 } attpc_run_stats;
 
 typedef struct attpc_ctx attpc_ctx;

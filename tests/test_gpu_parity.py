@@ -459,6 +459,7 @@ def test_full_size_properties(ctx):
         s2 = eng.run(n, seed=3)["stats"]
         for k in ("n_points", "charge_checksum", "key_checksum", "n_track_samples"):
             assert s1[k] == s2[k], k
+        assert s2["n_buffer_growths"] == 0  # sizes settle after the first run: no re-allocation in steady state
     assert s1["n_failed"] == 0 and s1["n_sample_limit"] == 0 and s1["n_inconsistent"] == 0
     assert 2000 < s1["n_points"] / n < 20000
     res = eng.run(64, seed=3, fetch=True)

@@ -181,9 +181,11 @@ struct __align__(16) ScatterShared {
 __device__ __forceinline__ const double* sample_ptr(const ScatterShared& sh, const double* arena, int n_sim, int c,
                                                     int& isim) {
   isim = 0;
+  (void)n_sim;  // cnt[k] = total for k >= n_sim (per-event init), so c >= cnt[k] is false there: no k < n_sim test,
+                // which cost seven loop-invariant lane masks in scalar registers (spilled, reloaded per call)
 #pragma unroll
   for (int k = 1; k < ATTPC_MAX_SIM; ++k)
-    if (k < n_sim && c >= sh.cnt[k]) isim = k;
+    if (c >= sh.cnt[k]) isim = k;
   const int s = c - sh.cnt[isim];
   const int blk = sh.blocks[isim][s / ARENA_BLK];
   return arena + ((size_t)blk * ARENA_BLK + (s & (ARENA_BLK - 1))) * 4;
@@ -1011,7 +1013,13 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
         PHASE_MARK(6);
         if (tid == 0 && sh.wg_cursor != n_rows) atomicAdd(&a.out.ctrl[CTRL_MISMATCH], 1ull);  // self-check, never seen
         const unsigned long long base = sh.base;
-        for (unsigned int r = tid; r < n_rows; r += SC_THREADS) {
+        // per-thread row pointers and the event id in VECTOR registers: as wave-uniform values they sat in
+        // scalar registers spilled to vector lanes, read back with one VALU instruction each per row
+        double* prow = a.out.points + (base + (unsigned long long)tid) * 3ull;
+        int64_t* plab = a.out.labels + (base + (unsigned long long)tid);
+        uint32_t ev_lo = (uint32_t)event, ev_hi = (uint32_t)(event >> 32);
+        asm volatile("" : "+v"(ev_lo), "+v"(ev_hi));
+        for (unsigned int r = tid; r < n_rows; r += SC_THREADS, prow += SC_THREADS * 3, plab += SC_THREADS) {
           const uint32_t slot = reinterpret_cast<const uint32_t*>(&sh.queue[0][0])[r];
           const uint32_t word = sh.keys[slot];
           const unsigned long long q = sh.chg[slot];
@@ -1020,16 +1028,20 @@ __global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) 
           const uint32_t key = word & KEY_MASK;
           const int pad = (int)(key & 0x3fffu), tb = (int)(key >> 14);
           my_charge += q;
-          my_keys += (event << 24) + (unsigned long long)key;
+          my_keys += (((unsigned long long)ev_hi << 32 | ev_lo) << 24) + (unsigned long long)key;
           if (base != ~0ull) {
-            const unsigned long long row = base + r;
             double ua, ub;
-            rng_pair<7>(a.seed, event, key, DOMAIN_JITTER, ua, ub);  // simulator.py:108
-            double* o = a.out.points + row * 3;
-            o[0] = (double)pad;
-            o[1] = (double)tb + ua;
-            o[2] = (double)q;
-            a.out.labels[row] = (int64_t)sh.label_of[word >> 24];  // from LDS: a global load here would
+            // The seed goes through an opaque asm per row: the 14 Philox round keys are then scalar adds inside
+            // the loop instead of 14 scalar registers held (and, at the limit of 102, spilled to vector lanes
+            // and read back with a VALU instruction each) across the whole kernel
+            uint32_t seed_lo = (uint32_t)a.seed, seed_hi = (uint32_t)(a.seed >> 32);
+            asm volatile("" : "+s"(seed_lo), "+s"(seed_hi));
+            rng_pair<7>((uint64_t)seed_lo | ((uint64_t)seed_hi << 32), (uint64_t)ev_lo | ((uint64_t)ev_hi << 32), key,
+                        DOMAIN_JITTER, ua, ub);  // simulator.py:108
+            prow[0] = (double)pad;
+            prow[1] = (double)tb + ua;
+            prow[2] = (double)q;
+            *plab = (int64_t)sh.label_of[word >> 24];  // from LDS: a global load here would
                                                                     // make every store wait (one vmcnt)
           }
         }

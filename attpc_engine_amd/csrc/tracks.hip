@@ -72,8 +72,11 @@ __device__ __forceinline__ void rhs(const double s[6], const Decomp& d, const Sp
 
 // PATH: the path-length sampling extension (DetDev::path_step > 0) -- its own instantiation, so that
 // the reference time-grid kernel keeps its register budget (167 VGPRs = 3 waves per SIMD) and its code.
+#ifndef ATTPC_TRACK_MIN_WAVES
+#define ATTPC_TRACK_MIN_WAVES 1  // waves per SIMD the register allocation must leave room for (experiments)
+#endif
 template <bool PATH>
-__global__ __launch_bounds__(TRACK_THREADS) void track_kernel(TrackArgs a) {
+__global__ __launch_bounds__(TRACK_THREADS, ATTPC_TRACK_MIN_WAVES) void track_kernel(TrackArgs a) {
   extern __shared__ double lds_tab[];  // [n_species][ATTPC_DEDX_NODES]
   const int n_tab = a.det.n_species * ATTPC_DEDX_NODES;
   for (int i = threadIdx.x; i < n_tab; i += TRACK_THREADS) lds_tab[i] = a.det.dedx[i];

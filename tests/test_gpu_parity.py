@@ -455,11 +455,13 @@ def test_full_size_properties(ctx):
     eng = _engine(inp, ctx)
     n = 50000
     s1 = eng.run(n, seed=3)["stats"]
-    for _ in range(12):  # soak: the scatter is full of LDS atomics and barrier-free hand-offs
+    for rep in range(12):  # soak: the scatter is full of LDS atomics and barrier-free hand-offs
         s2 = eng.run(n, seed=3)["stats"]
         for k in ("n_points", "charge_checksum", "key_checksum", "n_track_samples"):
             assert s1[k] == s2[k], k
-        assert s2["n_buffer_growths"] == 0  # sizes settle after the first run: no re-allocation in steady state
+        # the first run sizes the buffers with a pilot batch and chunk, the second one runs the full shape once;
+        # from then on nothing is re-allocated
+        assert rep == 0 or s2["n_buffer_growths"] == 0, (rep, s2["n_buffer_growths"])
     assert s1["n_failed"] == 0 and s1["n_sample_limit"] == 0 and s1["n_inconsistent"] == 0
     assert 2000 < s1["n_points"] / n < 20000
     res = eng.run(64, seed=3, fetch=True)

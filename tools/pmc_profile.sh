@@ -51,6 +51,29 @@ for kern, c in acc.items():
     for k, v in c.items():
         print(f"{kern:22s} {k:28s} {v / n:14.2f} per event")
 PY
+echo "---- track_kernel in batches of 8 scatter chunks (lane occupancy of the persistent-lane scheme) ----"
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d "$OUT/tracks8" -o run -- python3 bench.py --workload $WL --events 600000 --steps 1 --warmup 0 --no-cpu-baseline --no-delivered > "$OUT/tracks8.log" 2>&1 || echo "tracks8 pass failed"
+python3 - "$OUT" <<'PY'
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+per_dispatch = collections.OrderedDict()
+for f in sorted(glob.glob(out + "/tracks8/**/*counter_collection.csv", recursive=True)):
+    for row in csv.DictReader(open(f)):
+        if "track_kernel" in row["Kernel_Name"]:
+            d = per_dispatch.setdefault(row["Dispatch_Id"], {"grid": row.get("Grid_Size")})
+            d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+rows = []
+for disp, c in per_dispatch.items():
+    if c.get("SQ_INSTS_VALU"):
+        c["active_lanes_per_valu_instruction"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"] if c.get("SQ_THREAD_CYCLES_VALU") else None
+    rows.append(c)
+    print("track_kernel dispatch", disp, c)
+doc = json.load(open(out + "/pmc.json"))
+doc["track_kernel_batches"] = {"command": "bench.py --events 600000 --steps 1 --warmup 0 (pilot batch of 16 384 events, then 524 288 = 8 scatter chunks, then the rest)",
+                               "note": "active lanes of 64 = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU (scatter_kernel: 54)",
+                               "dispatches": rows}
+json.dump(doc, open(out + "/pmc.json", "w"), indent=1)
+PY
 echo "---- kernel-trace --stats of the default bench command ----"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 bench.py --workload $WL --no-cpu-baseline --no-delivered > "$OUT/stats_bench.json" 2> "$OUT/stats.err" || echo "stats run failed"
 for f in $(find "$OUT/stats" -name "*kernel_stats.csv"); do cp "$f" "$OUT/kernel_stats.csv"; cat "$f"; done

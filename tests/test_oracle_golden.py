@@ -390,3 +390,48 @@ def test_mc_diffusion_extension_oracle():
         # as whole cells) and which truncates per pixel
         assert 0.95 < ref[:, 2].sum() / pts[:, 2].sum() < 1.06
         assert abs(np.average(pts[:, 1], weights=pts[:, 2]) - np.average(ref[:, 1], weights=ref[:, 2])) < 2.0
+
+
+def test_path_step_extension_oracle(golden_dir):
+    """Path-length sampling (extension, BASELINE configs[4]; no reference counterpart: parity unpinned against
+    the reference) checked against the time-grid mode of the same oracle on the 14 fixture tracks: the two
+    modes integrate the same equation of motion with the same terminal events, so they must end in the same
+    place and lose the same energy; path mode samples are `path_step` apart (or 1e-10 s where the particle is
+    slower than path_step per 1e-10 s) and never coarser than the reference grid."""
+    g = np.load(golden_dir / "tracks.npz")
+    det, keep = _golden_det(g, fano=0.0)
+    species = [tuple(s) for s in g["species"]]
+    step = 2.5e-4
+    checked = 0
+    for i, case in enumerate(g["cases"]):
+        si = species.index((int(case[0]), int(case[1])))
+        det.path_step = 0.0
+        grid = orc.trajectory(det, si, case[5:8], g[f"mom{i}"])
+        det.path_step = step
+        path = orc.trajectory(det, si, case[5:8], g[f"mom{i}"])
+        det.path_step = 0.0
+        if len(grid) < 12:
+            continue
+        seg = np.linalg.norm(np.diff(path[:, :3], axis=0), axis=1)
+        assert seg.max() <= step * (1 + 1e-6)                      # never more than path_step apart ...
+        grid_seg = np.linalg.norm(np.diff(grid[:, :3], axis=0), axis=1)
+        fast = grid_seg[: len(grid_seg) // 2].min() > step          # ... and exactly path_step while the particle is fast
+        if fast:
+            np.testing.assert_allclose(seg[: min(20, len(seg))], step, rtol=2e-2)
+            assert len(path) > len(grid)
+        # same end point (within one sample spacing of either mode) and the same range
+        end_gap = np.linalg.norm(path[-1, :3] - grid[-1, :3])
+        assert end_gap <= max(grid_seg[-3:].max(), step) * 1.5 + 1e-6, (i, end_gap)
+        assert abs(seg.sum() - grid_seg.sum()) <= 2 * max(grid_seg.max(), step), i
+        mass = det.species[si].mass
+
+        def ke(rows):
+            return mass * (np.sqrt(1.0 + np.sum(rows[:, 3:] ** 2, axis=1)) - 1.0)
+
+        # energy along the way: at equal path length the two modes agree to 0.5 % of the initial energy
+        s_grid = np.concatenate([[0.0], np.cumsum(grid_seg)])
+        s_path = np.concatenate([[0.0], np.cumsum(seg)])
+        ke_path_at_grid = np.interp(s_grid, s_path, ke(path))
+        assert np.abs(ke_path_at_grid - ke(grid)).max() < 5e-3 * case[2], i
+        checked += 1
+    assert checked >= 12

@@ -250,6 +250,28 @@ def test_lone_time_bucket_larger_than_the_lds_table(ctx, orc, variant):
     print("variant", variant, "pads lit in the lone bucket:", lit, "lone buckets:", stats["n_lone_buckets"])
 
 
+def test_lone_time_bucket_with_monte_carlo_diffusion(ctx, orc):
+    """The same overflow with the per-electron Monte-Carlo diffusion extension (lone_bucket_kernel<true>): one
+    track (the oracle's diagnostic entry numbers the entries of a single track like the kernel does),
+    seed 0 / event 0 as orc_transport_track uses them."""
+    cfg, raw, keep = _configure(ctx, 0.277, mc_diffusion=True)
+    (xyt, el, lab), = _plane_filling_event(cfg, n_tracks=1, pitch_mm=4.8, electrons=20 * 175000)
+    assert len(xyt) <= 10112
+    ev = [(xyt, el, lab)]
+    clouds, stats = device_scatter(ctx, [ev], seed=0)
+    assert stats["n_failed"] == 0 and stats["n_inconsistent"] == 0 and stats["n_lone_buckets"] >= 1
+    keys, charge, labels = orc.transport(raw, ev)
+    tb, pad = np.array([orc.unpair(int(k)) for k in keys], dtype=np.int64).T
+    pts, lab_dev = clouds[0]
+    keep_ref = (tb >= 0) & (tb < 512)
+    order_ref = np.lexsort((tb[keep_ref], pad[keep_ref]))
+    order_dev = np.lexsort((np.floor(pts[:, 1]), pts[:, 0]))
+    np.testing.assert_array_equal(pts[order_dev, 0].astype(np.int64), pad[keep_ref][order_ref])
+    np.testing.assert_array_equal(pts[order_dev, 2].astype(np.int64), charge[keep_ref][order_ref])  # whole electrons: exact
+    assert len(pts) > 4096
+    _configure(ctx, 0.277)
+
+
 def test_pad_ids_outside_the_key_range_are_rejected(ctx):
     """a custom pad grid with ids >= 16384 (or < -1) must not corrupt keys silently."""
     gas = GasTarget([(1, 2, 2)], 300.0, nuclear_map)

@@ -164,7 +164,8 @@ EXPORTED_SYMBOLS = (
     "attpc_last_error", "attpc_set_chunk_events", "attpc_sync", "attpc_kin_configure",
     "attpc_kin_run", "attpc_kin_calculate", "attpc_decay_calculate", "attpc_det_configure", "attpc_det_run",
     "attpc_sim_run", "attpc_det_tracks", "attpc_spyral_rows", "attpc_spyral_configure", "attpc_sim_run_spyral",
-    "attpc_set_option", "attpc_host_alloc", "attpc_host_free", "attpc_det_scatter",
+    "attpc_set_option", "attpc_host_alloc", "attpc_host_free", "attpc_det_scatter", "attpc_unpack_rows",
+    "attpc_unpack_spyral_rows",
 )
 
 _lib = None
@@ -229,6 +230,9 @@ def load_library() -> C.CDLL:
     lib.attpc_set_option.argtypes = [ctxp, C.c_char_p, C.c_int64]
     lib.attpc_host_alloc.argtypes = [ctxp, C.c_uint64, C.POINTER(C.c_void_p)]
     lib.attpc_host_free.argtypes = [ctxp, C.c_void_p]
+    lib.attpc_unpack_rows.argtypes = [C.c_void_p, C.c_int64, _dp, C.POINTER(C.c_int64), C.c_int32]
+    lib.attpc_unpack_spyral_rows.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, C.c_int32, C.c_double, C.c_int32, C.c_int32,
+                                             C.c_double, _dp, C.POINTER(C.c_int64), C.c_int32]
     lib.attpc_spyral_rows.argtypes = [
         ctxp, C.c_int64, _dp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _dp,
     ]

@@ -24,7 +24,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "tracks_args.hpp"
@@ -57,8 +61,23 @@ struct AsmSet {  // one chunk's cloud in event order, or its Spyral rows
   int64_t* h_start = nullptr;  // pinned [h_start_len]: CSR offsets of the chunk (n + 1 entries)
   size_t h_start_len = 0;
   uint32_t* h_ev_rows = nullptr;  // pinned [h_start_len]: cloud rows of every event before any threshold
-  int64_t* h_total = nullptr;  // pinned [2]: rows in points / sp_rows
+  int64_t* h_total = nullptr;  // pinned [2]: [0] != 0: a row of the chunk does not fit the 16-byte transfer record
   hipEvent_t ready = nullptr, copied = nullptr;
+  // compact transfer: the chunk's rows as 16-byte records, device and (pinned, library-owned) host side, and the
+  // expansion into the caller's arrays that is still to be done once the copy has arrived
+  DevBuf packed;
+  void* h_packed = nullptr;
+  size_t h_packed_bytes = 0;
+  uint64_t unpack_ticket = 0;  // number of the expansion job that last used h_packed (0: none)
+};
+
+struct UnpackJob {  // one chunk's records in pinned staging -> the caller's arrays, once `copied` has fired
+  hipEvent_t copied = nullptr;
+  const void* src = nullptr;
+  int64_t rows = 0;
+  double* points = nullptr;   // [rows, 3] cloud rows, or [rows, 8] Spyral rows when `spyral`
+  int64_t* labels = nullptr;
+  bool spyral = false;
 };
 
 }  // namespace
@@ -73,6 +92,8 @@ struct attpc_ctx {
   int32_t chunk_events = 65536;
   int opt_variant = 0;             // 0 auto, 1 small, 2 big
   bool opt_tiny = false;
+  bool opt_compact = true;         // clouds cross PCIe as 16-byte records and are expanded by host threads
+  int opt_unpack_threads = 0;      // 0: min(16, hardware threads)
 
   bool kin_ready = false;
   attpc_kin_desc kin{};            // device pointers inside
@@ -100,8 +121,19 @@ struct attpc_ctx {
   bool spyral_ready = false;
   SpyralDev spyral{};
   std::vector<void*> spyral_allocs;
+  std::vector<double> h_pad_centers, h_pad_sizes;  // host copies: the expansion of compact Spyral records needs them
   DevBuf scratch[8];
   std::vector<void*> host_allocs;  // attpc_host_alloc
+
+  // expansion of compact transfer records: one helper thread takes the jobs in order (it waits for the copy,
+  // then fans the rows out over worker threads), so that the thread driving the GPU never stands in a memcpy
+  // while the copy engine waits for its next order
+  std::thread unpacker;
+  std::mutex unpack_mutex;
+  std::condition_variable unpack_cv;
+  std::deque<UnpackJob> unpack_jobs;
+  uint64_t unpack_submitted = 0, unpack_done = 0;
+  bool unpack_stop = false, unpack_failed = false;
 };
 
 namespace {
@@ -240,6 +272,110 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const Segment* __r
     int64_t* dst_l = out_labels + dst;
     for (int i = threadIdx.x; i < sg.count; i += 256) dst_l[i] = src_l[i];
   }
+}
+
+// ---- compact transfer of delivered clouds ----
+// A cloud row in the reference's dtypes is 3 f64 + i64 = 32 bytes, but it holds 14 bits of pad, 5 of label, an
+// integer charge and one real number (the jittered time bucket): 16 bytes carry it losslessly --
+//   word 0 = the f64 time bucket + jitter as it is, word 1 = charge (45 bits) | pad << 45 (14) | label << 59 (5).
+// The delivered path is PCIe bound (234 KB per event in the reference's dtypes), so the chunk crosses the link in
+// this form into library-owned pinned staging and host threads expand it into the caller's arrays -- which then
+// need not be page-locked either.  A chunk with a row that does not fit (charge >= 2^45, label >= 32) goes the
+// plain way.
+struct PackedRow {
+  double tb;
+  unsigned long long bits;
+};
+constexpr int PACK_CHARGE_BITS = 45, PACK_PAD_BITS = 14;
+
+__global__ __launch_bounds__(256) void pack_rows_kernel(const int64_t* __restrict__ ev_start, uint32_t n_events,
+                                                        const double* __restrict__ points, const int64_t* __restrict__ labels,
+                                                        PackedRow* __restrict__ packed, int64_t* __restrict__ flag) {
+  const int64_t total = ev_start[n_events];
+  bool bad = false;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < total; r += (int64_t)gridDim.x * 256) {
+    const double padf = points[3 * r], q = points[3 * r + 2];
+    const long long label = labels[r];
+    const unsigned long long charge = (unsigned long long)q, pad = (unsigned long long)padf;
+    bad = bad || !(q >= 0.0) || charge >= (1ull << PACK_CHARGE_BITS) || pad >= (1ull << PACK_PAD_BITS) || label < 0 || label >= 32;
+    PackedRow row;
+    row.tb = points[3 * r + 1];
+    row.bits = (charge & ((1ull << PACK_CHARGE_BITS) - 1)) | (pad << PACK_CHARGE_BITS) |
+               ((unsigned long long)label << (PACK_CHARGE_BITS + PACK_PAD_BITS));
+    packed[r] = row;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(flag), 1ull);
+}
+
+void unpack_slice(const PackedRow* src, int64_t lo, int64_t hi, double* points, int64_t* labels) {
+  // streaming (non-temporal) stores: the expanded rows are written once and read by somebody else later, so
+  // they should not be read into this core's cache first (half the memory traffic of ordinary stores)
+  for (int64_t r = lo; r < hi; ++r) {
+    const unsigned long long b = src[r].bits;
+    __builtin_nontemporal_store((double)((b >> PACK_CHARGE_BITS) & ((1ull << PACK_PAD_BITS) - 1)), &points[3 * r]);
+    __builtin_nontemporal_store(src[r].tb, &points[3 * r + 1]);
+    __builtin_nontemporal_store((double)(b & ((1ull << PACK_CHARGE_BITS) - 1)), &points[3 * r + 2]);
+    __builtin_nontemporal_store((long long)(b >> (PACK_CHARGE_BITS + PACK_PAD_BITS)), reinterpret_cast<long long*>(&labels[r]));
+  }
+}
+
+void unpack_rows(const PackedRow* src, int64_t n, double* points, int64_t* labels, int n_threads) {
+  if (n_threads <= 0) n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n / 65536));
+  if (n_threads <= 1) {
+    unpack_slice(src, 0, n, points, labels);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const int64_t per = (n + n_threads - 1) / n_threads;
+  for (int t = 1; t < n_threads; ++t)
+    pool.emplace_back(unpack_slice, src, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per), points, labels);
+  unpack_slice(src, 0, std::min<int64_t>(n, per), points, labels);
+  for (std::thread& th : pool) th.join();
+}
+
+struct SpyralHostTables {  // what convert_to_spyral (writer.py:61-112) needs beside the record
+  const double* centers;    // [n_pads, 2]
+  const double* sizes;      // [n_pads]
+  int32_t n_pads;
+  double r_max, window_edge, mm_edge, length;
+};
+
+void unpack_spyral_slice(const SpyralPacked* src, int64_t lo, int64_t hi, SpyralHostTables t, double* rows, int64_t* labels) {
+  for (int64_t r = lo; r < hi; ++r) {
+    const unsigned long long b = src[r].bits;
+    int pad = (int)((b >> SPYRAL_PACK_CHARGE_BITS) & ((1ull << SPYRAL_PACK_PAD_BITS) - 1));
+    pad = pad >= t.n_pads ? t.n_pads - 1 : pad;
+    const double q = (double)(b & ((1ull << SPYRAL_PACK_CHARGE_BITS) - 1));
+    const double tb = src[r].tb;
+    double amp = t.r_max * q;  // detector/response.py:55-57 (maximum of the clipped samples), as spyral.hip amplitude()
+    amp = amp > 4095.0 ? 4095.0 : amp;
+    double* row = rows + 8 * r;
+    __builtin_nontemporal_store(t.centers[2 * pad], &row[0]);
+    __builtin_nontemporal_store(t.centers[2 * pad + 1], &row[1]);
+    __builtin_nontemporal_store((t.window_edge - tb) / (t.window_edge - t.mm_edge) * t.length * 1000.0, &row[2]);  // writer.py:103-105
+    __builtin_nontemporal_store(amp, &row[3]);
+    __builtin_nontemporal_store(src[r].integral, &row[4]);
+    __builtin_nontemporal_store((double)pad, &row[5]);
+    __builtin_nontemporal_store(tb, &row[6]);
+    __builtin_nontemporal_store(t.sizes[pad], &row[7]);
+    __builtin_nontemporal_store((long long)(b >> (SPYRAL_PACK_CHARGE_BITS + SPYRAL_PACK_PAD_BITS)), reinterpret_cast<long long*>(&labels[r]));
+  }
+}
+
+void unpack_spyral_rows(const SpyralPacked* src, int64_t n, const SpyralHostTables& t, double* rows, int64_t* labels, int n_threads) {
+  if (n_threads <= 0) n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n / 32768));
+  if (n_threads <= 1) {
+    unpack_spyral_slice(src, 0, n, t, rows, labels);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const int64_t per = (n + n_threads - 1) / n_threads;
+  for (int k = 1; k < n_threads; ++k)
+    pool.emplace_back(unpack_spyral_slice, src, std::min<int64_t>(n, k * per), std::min<int64_t>(n, (k + 1) * per), t, rows, labels);
+  unpack_spyral_slice(src, 0, std::min<int64_t>(n, per), t, rows, labels);
+  for (std::thread& th : pool) th.join();
 }
 
 __global__ __launch_bounds__(256) void count_status_kernel(const int32_t* __restrict__ status, uint32_t n,
@@ -579,6 +715,16 @@ int32_t enqueue_assembly(attpc_ctx* ctx, int slot, AsmSet& as, uint32_t n, bool 
   HIP_TRY(ctx, hipMemcpyAsync(as.h_ev_rows, ctx->ev_rows.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   if (!spyral) {
     HIP_TRY(ctx, hipMemcpyAsync(as.h_start, as.ev_start.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->opt_compact) {
+      if ((rc = ensure(ctx, as.packed, cap * sizeof(PackedRow) + 2 * sizeof(int64_t)))) return rc;
+      int64_t* d_flag = reinterpret_cast<int64_t*>(static_cast<char*>(as.packed.p) + cap * sizeof(PackedRow));
+      HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 2 * sizeof(int64_t), ctx->stream));
+      hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)ctx->n_cus * 8u), dim3(256), 0, ctx->stream,
+                         static_cast<const int64_t*>(as.ev_start.p), n, static_cast<const double*>(as.points.p),
+                         static_cast<const int64_t*>(as.labels.p), static_cast<PackedRow*>(as.packed.p), d_flag);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipMemcpyAsync(as.h_total, d_flag, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
   } else {
     if ((rc = ensure(ctx, as.kept, (size_t)n * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, as.kept_start, ((size_t)n + 1) * sizeof(int64_t)))) return rc;
@@ -593,17 +739,85 @@ int32_t enqueue_assembly(attpc_ctx* ctx, int slot, AsmSet& as, uint32_t n, bool 
                        static_cast<int64_t*>(as.kept_start.p), static_cast<int64_t*>(nullptr),
                        static_cast<const unsigned long long*>(nullptr));
     HIP_TRY(ctx, hipGetLastError());
+    SpyralPacked* d_packed = nullptr;
+    int64_t* d_flag = nullptr;
+    if (ctx->opt_compact) {  // 24-byte records instead of rows of 8 doubles + label; the flag sits behind them
+      if ((rc = ensure(ctx, as.packed, cap * sizeof(SpyralPacked) + 2 * sizeof(int64_t)))) return rc;
+      d_packed = static_cast<SpyralPacked*>(as.packed.p);
+      d_flag = reinterpret_cast<int64_t*>(static_cast<char*>(as.packed.p) + cap * sizeof(SpyralPacked));
+      HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 2 * sizeof(int64_t), ctx->stream));
+    }
     launch_spyral_write(ctx->stream, ctx->spyral, n, static_cast<const int64_t*>(as.ev_start.p),
                         static_cast<const int64_t*>(as.kept_start.p), static_cast<const double*>(as.points.p),
                         static_cast<const int64_t*>(as.labels.p), static_cast<double*>(as.sp_rows.p),
                         static_cast<int64_t*>(as.sp_labels.p), static_cast<uint32_t*>(ctx->sort_idx.p),
-                        static_cast<double*>(ctx->sort_key.p));
+                        static_cast<double*>(ctx->sort_key.p), d_packed, d_flag);
     HIP_TRY(ctx, hipGetLastError());
+    if (ctx->opt_compact) HIP_TRY(ctx, hipMemcpyAsync(as.h_total, d_flag, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(as.h_start, as.kept_start.p, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
   }
   HIP_TRY(ctx, hipEventRecord(as.ready, ctx->stream));
   return ATTPC_OK;
 }
+
+void unpacker_main(attpc_ctx* ctx) {
+  (void)hipSetDevice(ctx->device);
+  for (;;) {
+    UnpackJob job;
+    {
+      std::unique_lock<std::mutex> lock(ctx->unpack_mutex);
+      ctx->unpack_cv.wait(lock, [&] { return ctx->unpack_stop || !ctx->unpack_jobs.empty(); });
+      if (ctx->unpack_jobs.empty()) return;  // stop requested and nothing left
+      job = ctx->unpack_jobs.front();
+      ctx->unpack_jobs.pop_front();
+    }
+    const bool ok = hipEventSynchronize(job.copied) == hipSuccess;
+    if (ok && job.spyral) {
+      SpyralHostTables t;
+      t.centers = ctx->h_pad_centers.data();
+      t.sizes = ctx->h_pad_sizes.data();
+      t.n_pads = ctx->spyral.n_pads;
+      t.r_max = ctx->spyral.r_max;
+      t.window_edge = ctx->spyral.window_edge;
+      t.mm_edge = ctx->spyral.mm_edge;
+      t.length = ctx->spyral.length;
+      unpack_spyral_rows(static_cast<const SpyralPacked*>(job.src), job.rows, t, job.points, job.labels, ctx->opt_unpack_threads);
+    } else if (ok) {
+      unpack_rows(static_cast<const PackedRow*>(job.src), job.rows, job.points, job.labels, ctx->opt_unpack_threads);
+    }
+    {
+      std::lock_guard<std::mutex> lock(ctx->unpack_mutex);
+      ctx->unpack_done++;
+      if (!ok) ctx->unpack_failed = true;
+    }
+    ctx->unpack_cv.notify_all();
+  }
+}
+
+uint64_t submit_unpack(attpc_ctx* ctx, const UnpackJob& job) {
+  uint64_t ticket;
+  {
+    std::lock_guard<std::mutex> lock(ctx->unpack_mutex);
+    if (!ctx->unpacker.joinable()) ctx->unpacker = std::thread(unpacker_main, ctx);
+    ctx->unpack_jobs.push_back(job);
+    ticket = ++ctx->unpack_submitted;
+  }
+  ctx->unpack_cv.notify_all();
+  return ticket;
+}
+
+int32_t wait_unpacked(attpc_ctx* ctx, uint64_t ticket);
+
+// Every run entry point holds one of these: whatever way the call ends, no expansion job may outlive it (the
+// jobs write into the caller's arrays).
+struct UnpackDrain {
+  attpc_ctx* ctx;
+  explicit UnpackDrain(attpc_ctx* c) : ctx(c) {}
+  ~UnpackDrain() {
+    std::unique_lock<std::mutex> lock(ctx->unpack_mutex);
+    ctx->unpack_cv.wait(lock, [&] { return ctx->unpack_done >= ctx->unpack_submitted; });
+  }
+};
 
 // The chunk in `as` is ready on the device: write its offsets, queue its copy to the caller's arrays on C.
 int32_t deliver_chunk(attpc_ctx* ctx, AsmSet& as, uint32_t n, uint64_t chunk_first_local, bool spyral, attpc_cloud_out* out,
@@ -620,7 +834,42 @@ int32_t deliver_chunk(attpc_ctx* ctx, AsmSet& as, uint32_t n, uint64_t chunk_fir
     HIP_TRY(ctx, hipEventRecord(as.copied, ctx->stream_c));
     return ATTPC_OK;
   }
-  if (total > 0) {
+  const bool compact = ctx->opt_compact && as.h_total[0] == 0;  // [0]: a row of the chunk does not fit the record
+  if (total > 0 && spyral && ctx->opt_compact && !compact) {
+    // the write kernel produced records only: produce the rows themselves for the plain copy below (rare)
+    launch_spyral_write(ctx->stream, ctx->spyral, n, static_cast<const int64_t*>(as.ev_start.p),
+                        static_cast<const int64_t*>(as.kept_start.p), static_cast<const double*>(as.points.p),
+                        static_cast<const int64_t*>(as.labels.p), static_cast<double*>(as.sp_rows.p),
+                        static_cast<int64_t*>(as.sp_labels.p), static_cast<uint32_t*>(ctx->sort_idx.p),
+                        static_cast<double*>(ctx->sort_key.p), nullptr, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (total > 0 && compact) {
+    const size_t bytes = (size_t)total * (spyral ? sizeof(SpyralPacked) : sizeof(PackedRow));
+    {  // the staging's previous occupant (two chunks back) must have been expanded
+      int32_t rcw = wait_unpacked(ctx, as.unpack_ticket);
+      if (rcw) return rcw;
+    }
+    if (bytes > as.h_packed_bytes) {  // library-owned pinned staging, grow-only with headroom
+      if (as.h_packed) HIP_TRY(ctx, hipHostFree(as.h_packed));
+      as.h_packed = nullptr;
+      as.h_packed_bytes = 0;
+      HIP_TRY(ctx, hipHostMalloc(&as.h_packed, bytes + bytes / 4, hipHostMallocDefault));
+      as.h_packed_bytes = bytes + bytes / 4;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(as.h_packed, as.packed.p, bytes, hipMemcpyDeviceToHost, ctx->stream_c));
+    HIP_TRY(ctx, hipEventRecord(as.copied, ctx->stream_c));
+    UnpackJob job;
+    job.copied = as.copied;
+    job.src = as.h_packed;
+    job.rows = total;
+    job.points = out->points + base * (spyral ? 8 : 3);
+    job.labels = out->labels + base;
+    job.spyral = spyral;
+    as.unpack_ticket = submit_unpack(ctx, job);
+    return ATTPC_OK;
+  } else if (total > 0) {
     const size_t width = spyral ? 8 : 3;
     HIP_TRY(ctx, hipMemcpyAsync(out->points + base * width, spyral ? as.sp_rows.p : as.points.p, (size_t)total * width * sizeof(double),
                                 hipMemcpyDeviceToHost, ctx->stream_c));
@@ -628,6 +877,15 @@ int32_t deliver_chunk(attpc_ctx* ctx, AsmSet& as, uint32_t n, uint64_t chunk_fir
                                 hipMemcpyDeviceToHost, ctx->stream_c));
   }
   HIP_TRY(ctx, hipEventRecord(as.copied, ctx->stream_c));
+  return ATTPC_OK;
+}
+
+// Wait until expansion job `ticket` (and every earlier one) is done: the staging it read is free again and its
+// rows are in the caller's arrays.
+int32_t wait_unpacked(attpc_ctx* ctx, uint64_t ticket) {
+  std::unique_lock<std::mutex> lock(ctx->unpack_mutex);
+  ctx->unpack_cv.wait(lock, [&] { return ctx->unpack_done >= ticket || ctx->unpack_failed; });
+  if (ctx->unpack_failed) return fail(ctx, ATTPC_E_HIP, "waiting for a device-to-host copy failed in the expansion thread");
   return ATTPC_OK;
 }
 
@@ -774,12 +1032,14 @@ int32_t run_batch_chunks(attpc_ctx* ctx, const attpc_event_layout& lay, const Tr
     }
   }
   if (prev.slot >= 0 && (rc = complete(prev, prev_set))) return rc;
+  if ((rc = wait_unpacked(ctx, ctx->unpack_submitted))) return rc;  // every row is in the caller's arrays
   return queue_next_once();
 }
 
 int32_t run_events(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events, const attpc_event_layout& lay,
                    const RunSource& src, const RunSink& sink, attpc_cloud_out* out, bool spyral, attpc_run_stats* stats) {
   int32_t rc;
+  UnpackDrain drain(ctx);
   attpc_run_stats st{};
   st.n_events = n_events;
   const uint64_t growths_before = ctx->n_growths;
@@ -893,6 +1153,12 @@ int32_t attpc_ctx_create(int32_t device, attpc_ctx** out) {
 int32_t attpc_ctx_destroy(attpc_ctx* ctx) {
   if (!ctx) return ATTPC_OK;
   (void)hipSetDevice(ctx->device);
+  {
+    std::lock_guard<std::mutex> lock(ctx->unpack_mutex);
+    ctx->unpack_stop = true;
+  }
+  ctx->unpack_cv.notify_all();
+  if (ctx->unpacker.joinable()) ctx->unpacker.join();
   if (ctx->stream_t) (void)hipStreamSynchronize(ctx->stream_t);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream_c) (void)hipStreamSynchronize(ctx->stream_c);
@@ -910,7 +1176,8 @@ int32_t attpc_ctx_destroy(attpc_ctx* ctx) {
     if (ts.h_ctrl) (void)hipHostFree(ts.h_ctrl);
   }
   for (AsmSet& as : ctx->aset) {
-    for (DevBuf* b : {&as.ev_start, &as.points, &as.labels, &as.kept, &as.kept_start, &as.sp_rows, &as.sp_labels}) bufs.push_back(b);
+    for (DevBuf* b : {&as.ev_start, &as.points, &as.labels, &as.kept, &as.kept_start, &as.sp_rows, &as.sp_labels, &as.packed}) bufs.push_back(b);
+    if (as.h_packed) (void)hipHostFree(as.h_packed);
     for (hipEvent_t e : {as.ready, as.copied})
       if (e) (void)hipEventDestroy(e);
     if (as.h_start) (void)hipHostFree(as.h_start);
@@ -950,6 +1217,11 @@ int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value) {
     ctx->opt_variant = (int)value;
   } else if (key == "tiny_buffers") {
     ctx->opt_tiny = value != 0;
+  } else if (key == "compact_transfer") {
+    ctx->opt_compact = value != 0;
+  } else if (key == "unpack_threads") {
+    if (value < 0 || value > 1024) return fail(ctx, ATTPC_E_INVALID, "unpack_threads must be 0..1024");
+    ctx->opt_unpack_threads = (int)value;
   } else if (key == "chunk_events") {
     return attpc_set_chunk_events(ctx, (int32_t)value);
   } else {
@@ -978,6 +1250,28 @@ int32_t attpc_host_free(attpc_ctx* ctx, void* ptr) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
   HIP_TRY(ctx, hipHostFree(ptr));
   ctx->host_allocs.erase(it);
+  return ATTPC_OK;
+}
+
+int32_t attpc_unpack_rows(const void* packed, int64_t n_rows, double* points, int64_t* labels, int32_t n_threads) {
+  if (n_rows < 0 || (n_rows > 0 && (!packed || !points || !labels))) return ATTPC_E_INVALID;
+  unpack_rows(static_cast<const PackedRow*>(packed), n_rows, points, labels, n_threads);
+  return ATTPC_OK;
+}
+
+int32_t attpc_unpack_spyral_rows(const void* packed, int64_t n_rows, const double* pad_centers, const double* pad_sizes,
+                                 int32_t n_pads, double r_max, int32_t windows_edge, int32_t micromegas_edge, double length,
+                                 double* rows, int64_t* labels, int32_t n_threads) {
+  if (n_rows < 0 || n_pads < 1 || (n_rows > 0 && (!packed || !pad_centers || !pad_sizes || !rows || !labels))) return ATTPC_E_INVALID;
+  SpyralHostTables t;
+  t.centers = pad_centers;
+  t.sizes = pad_sizes;
+  t.n_pads = n_pads;
+  t.r_max = r_max;
+  t.window_edge = (double)windows_edge;
+  t.mm_edge = (double)micromegas_edge;
+  t.length = length;
+  unpack_spyral_rows(static_cast<const SpyralPacked*>(packed), n_rows, t, rows, labels, n_threads);
   return ATTPC_OK;
 }
 
@@ -1242,6 +1536,8 @@ int32_t attpc_spyral_configure(attpc_ctx* ctx, const attpc_spyral_desc* d) {
   if ((rc = upload(ctx, ctx->spyral_allocs, prefix.data(), prefix.size(), &sp.prefix))) return rc;
   if ((rc = upload(ctx, ctx->spyral_allocs, d->pad_centers, (size_t)d->n_pads * 2, &sp.pad_centers))) return rc;
   if ((rc = upload(ctx, ctx->spyral_allocs, d->pad_sizes, (size_t)d->n_pads, &sp.pad_sizes))) return rc;
+  ctx->h_pad_centers.assign(d->pad_centers, d->pad_centers + (size_t)d->n_pads * 2);
+  ctx->h_pad_sizes.assign(d->pad_sizes, d->pad_sizes + (size_t)d->n_pads);
   sp.n_pads = d->n_pads;
   sp.r_max = sorted[0];
   sp.total = prefix[ATTPC_NUM_TB];
@@ -1341,6 +1637,7 @@ int32_t attpc_det_scatter(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, u
   trk.block_table = static_cast<int32_t*>(ts.block_table.p);
   trk.counts = static_cast<int32_t*>(ts.counts.p);
   trk.arena_blocks = (uint32_t)ts.arena_blocks;
+  UnpackDrain drain(ctx);
   attpc_run_stats st{};
   st.n_events = n_events;
   int64_t row_cursor = 0;

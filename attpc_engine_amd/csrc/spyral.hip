@@ -70,7 +70,9 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, 
                                                                    double* __restrict__ rows,
                                                                    int64_t* __restrict__ out_labels,
                                                                    uint32_t* __restrict__ sort_idx,
-                                                                   double* __restrict__ sort_key) {
+                                                                   double* __restrict__ sort_key,
+                                                                   SpyralPacked* __restrict__ packed,
+                                                                   int64_t* __restrict__ pack_flag) {
   __shared__ uint32_t bin_cursor[SORT_BINS];     // counts, then the next free position of every bin
   __shared__ uint32_t bin_start[SORT_BINS + 1];
   __shared__ uint32_t wave_total[SP_THREADS / 64];
@@ -142,6 +144,19 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, 
     const double padf = points[3 * r], q_el = points[3 * r + 2];
     int pad = (int)padf;
     pad = pad < 0 ? 0 : (pad >= sp.n_pads ? sp.n_pads - 1 : pad);
+    if (packed != nullptr) {  // compact transfer (tracks_args.hpp): the host expands this to the 8-column row
+      const long long label = labels[r];
+      const unsigned long long charge = (unsigned long long)q_el;
+      if (!(q_el >= 0.0) || charge >= (1ull << SPYRAL_PACK_CHARGE_BITS) || padf != (double)pad || label < 0 || label >= 32)
+        atomicMax(reinterpret_cast<unsigned long long*>(pack_flag), 1ull);
+      SpyralPacked rec;
+      rec.tb = tb;
+      rec.bits = (charge & ((1ull << SPYRAL_PACK_CHARGE_BITS) - 1)) | ((unsigned long long)pad << SPYRAL_PACK_CHARGE_BITS) |
+                 ((unsigned long long)label << (SPYRAL_PACK_CHARGE_BITS + SPYRAL_PACK_PAD_BITS));
+      rec.integral = clipped_integral(sp, q_el);
+      packed[o] = rec;
+      continue;
+    }
     double* row = rows + 8 * o;
     row[0] = sp.pad_centers[2 * pad];
     row[1] = sp.pad_centers[2 * pad + 1];
@@ -161,9 +176,9 @@ void launch_spyral_count(hipStream_t s, const SpyralDev& sp, uint32_t n_events, 
 }
 void launch_spyral_write(hipStream_t s, const SpyralDev& sp, uint32_t n_events, const int64_t* event_start,
                          const int64_t* kept_start, const double* points, const int64_t* labels, double* rows,
-                         int64_t* out_labels, uint32_t* sort_idx, double* sort_key) {
+                         int64_t* out_labels, uint32_t* sort_idx, double* sort_key, SpyralPacked* packed, int64_t* pack_flag) {
   hipLaunchKernelGGL(spyral_write_kernel, dim3(n_events), dim3(SP_THREADS), 0, s, sp, event_start, kept_start, points,
-                     labels, rows, out_labels, sort_idx, sort_key);
+                     labels, rows, out_labels, sort_idx, sort_key, packed, pack_flag);
 }
 
 }  // namespace attpc

@@ -213,6 +213,10 @@ ATTPC_API int32_t attpc_sync(attpc_ctx* ctx);
  *                      one-workgroup build of the scatter kernel
  *   "tiny_buffers"     != 0: the next buffers are allocated far too small (exercises the
  *                      grow-and-rerun path in tests)
+ *   "compact_transfer" != 0 (default): delivered clouds cross PCIe as 16-byte records (attpc_unpack_rows) into
+ *                      library-owned pinned staging and are expanded into the caller's arrays by host threads;
+ *                      0: rows are copied in the reference's dtypes (32 bytes) straight into the caller's arrays
+ *   "unpack_threads"   host threads of that expansion; 0 (default) = min(16, hardware threads)
  *   "chunk_events"     as attpc_set_chunk_events */
 ATTPC_API int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value);
 /* Page-locked host memory for output buffers (point clouds are PCIe bound on their way to the host:
@@ -220,6 +224,21 @@ ATTPC_API int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t val
  * Plain memory otherwise: the caller reads/writes it freely and returns it with attpc_host_free. */
 ATTPC_API int32_t attpc_host_alloc(attpc_ctx* ctx, uint64_t bytes, void** out);
 ATTPC_API int32_t attpc_host_free(attpc_ctx* ctx, void* ptr);
+/* The 16-byte transfer record of a cloud row and its expansion (host only, no device, no context):
+ *   bytes 0..7   f64  time bucket + jitter (column 1 of the row, as it is)
+ *   bytes 8..15  u64  electrons (bits 0..44) | pad << 45 (14 bits) | label << 59 (5 bits)
+ * -> points[r] = (pad, time bucket, electrons) as f64, labels[r] as i64 (detector/simulator.py:40-46). */
+ATTPC_API int32_t attpc_unpack_rows(const void* packed, int64_t n_rows, double* points, int64_t* labels, int32_t n_threads);
+/* The 24-byte transfer record of a Spyral row (attpc_sim_run_spyral with "compact_transfer") and its expansion
+ * to the 8 columns of convert_to_spyral (detector/writer.py:61-112), host only:
+ *   bytes 0..7 f64 time bucket + jitter, 8..15 u64 electrons | pad << 45 | label << 59, 16..23 f64 clipped integral
+ * -> x, y = pad_centers[pad], z = (windows_edge - tb) / (windows_edge - micromegas_edge) * length * 1000,
+ *    amplitude = min(r_max * electrons, 4095) with r_max the largest response sample, integral, pad, tb,
+ *    pad_sizes[pad]; labels[r] as i64. */
+ATTPC_API int32_t attpc_unpack_spyral_rows(const void* packed, int64_t n_rows, const double* pad_centers,
+                                           const double* pad_sizes, int32_t n_pads, double r_max, int32_t windows_edge,
+                                           int32_t micromegas_edge, double length, double* rows, int64_t* labels,
+                                           int32_t n_threads);
 
 /* KinematicsPipeline(...) state -> device.  kinematics/pipeline.py:125-185 */
 ATTPC_API int32_t attpc_kin_configure(attpc_ctx* ctx, const attpc_kin_desc* desc);

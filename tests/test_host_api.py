@@ -261,3 +261,71 @@ def test_kinematics_file_roundtrip(tmp_path):
     v, q = r.read(3, 8)
     np.testing.assert_array_equal(v, vertex[3:8])
     np.testing.assert_array_equal(q, p4[3:8])
+
+
+def test_transfer_record_unpack():
+    """The 16-byte transfer record of a cloud row (include/attpc_engine.h, attpc_unpack_rows): a pure host
+    function of the library, so the layout is pinned without a GPU -- all field extremes, many threads."""
+    import ctypes as C
+    lib = _abi.load_library()
+    rng = np.random.default_rng(5)
+    n = 300_001
+    pad = rng.integers(0, 1 << 14, size=n).astype(np.uint64)
+    label = rng.integers(0, 32, size=n).astype(np.uint64)
+    charge = rng.integers(0, 1 << 45, size=n, dtype=np.uint64)
+    tb = rng.uniform(0.0, 512.0, size=n)
+    pad[:4] = [0, (1 << 14) - 1, 0, (1 << 14) - 1]
+    label[:4] = [0, 31, 31, 0]
+    charge[:4] = [0, (1 << 45) - 1, 0, (1 << 45) - 1]
+    packed = np.empty(n, dtype=[("tb", np.float64), ("bits", np.uint64)])
+    packed["tb"] = tb
+    packed["bits"] = charge | (pad << np.uint64(45)) | (label << np.uint64(59))
+    for threads in (1, 0, 7):
+        points = np.full((n, 3), -1.0)
+        labels = np.full(n, -1, dtype=np.int64)
+        rc = lib.attpc_unpack_rows(packed.ctypes.data_as(C.c_void_p), n, _abi.dptr(points), _abi.iptr(labels, C.c_int64), threads)
+        assert rc == 0
+        np.testing.assert_array_equal(points[:, 0], pad.astype(np.float64))
+        np.testing.assert_array_equal(points[:, 1], tb)
+        np.testing.assert_array_equal(points[:, 2], charge.astype(np.float64))
+        np.testing.assert_array_equal(labels, label.astype(np.int64))
+    assert lib.attpc_unpack_rows(None, 0, None, None, 1) == 0
+
+
+def test_spyral_transfer_record_unpack(golden_dir):
+    """attpc_unpack_spyral_rows against convert_to_spyral (the oracle's restatement, itself pinned to the rows the
+    reference's own writer.convert_to_spyral made, tests/golden/response.npz): the 24-byte record holds (tb,
+    electrons | pad | label, integral); x, y, z, amplitude, pad scale are rebuilt on the host.  Pure host code:
+    runs without a GPU.  Charges are whole numbers, as everywhere in the pipeline."""
+    import ctypes as C
+    from attpc_engine_amd import GasTarget, nuclear_map
+    from attpc_engine_amd.workloads import detector_config
+    from oracle import pyoracle as orc
+    lib = _abi.load_library()
+    g = np.load(golden_dir / "response.npz")
+    cfg = detector_config(GasTarget([(1, 2, 2)], 300.0, nuclear_map))
+    rng = np.random.default_rng(9)
+    n = 5000
+    pts = np.column_stack([rng.integers(0, 10240, n).astype(np.float64), rng.uniform(0.0, 512.0, n),
+                           np.floor(10.0 ** rng.uniform(0.0, 9.5, n))])
+    pts[:len(g["points"]), :2] = g["points"][:, :2]
+    pts[:len(g["points"]), 2] = np.floor(g["points"][:, 2])
+    response = np.ascontiguousarray(g["response"])
+    centers = np.ascontiguousarray(cfg.pad_centers, dtype=np.float64)
+    sizes = np.ascontiguousarray(cfg.pad_sizes, dtype=np.float64)
+    want = np.empty((n, 8))
+    orc.lib().orc_convert_to_spyral(_abi.dptr(np.ascontiguousarray(pts)), n, 560, 10, 1.0, _abi.dptr(response), _abi.dptr(centers),
+                                    _abi.dptr(sizes), _abi.dptr(want))
+    labels_in = (np.arange(n) % 18).astype(np.uint64)
+    packed = np.empty(n, dtype=[("tb", np.float64), ("bits", np.uint64), ("integral", np.float64)])
+    packed["tb"] = pts[:, 1]
+    packed["bits"] = pts[:, 2].astype(np.uint64) | (pts[:, 0].astype(np.uint64) << np.uint64(45)) | (labels_in << np.uint64(59))
+    packed["integral"] = want[:, 4]
+    rows = np.empty((n, 8))
+    labels = np.empty(n, dtype=np.int64)
+    rc = lib.attpc_unpack_spyral_rows(packed.ctypes.data_as(C.c_void_p), n, _abi.dptr(centers), _abi.dptr(sizes), len(sizes),
+                                      float(response.max()), 560, 10, 1.0, _abi.dptr(rows), _abi.iptr(labels, C.c_int64), 3)
+    assert rc == 0
+    np.testing.assert_array_equal(rows, want)  # table look-ups, one subtraction / division / two products, one clipped product
+    np.testing.assert_array_equal(labels, labels_in.astype(np.int64))
+    assert (want[:, 3] == 4095.0).any() and (want[:, 3] < 40.0).any()

@@ -754,6 +754,35 @@ def test_fused_spyral_rows(tmp_path, ctx, orc):
     assert all(c[1] == 0 and c[2] for c in log.calls[:-1]) and len(log.calls) > n // 2
 
 
+def test_spyral_delivery_plain_and_compact_agree(ctx):
+    """The fused Spyral path delivers 24-byte transfer records by default; with `compact_transfer` off it copies
+    the rows of 8 doubles themselves.  Same rows -- also when the charges do not fit the record (a gain of 1e11:
+    electrons x gain beyond 2^45) and the chunk falls back to the plain copy after a second pass of the kernel."""
+    import copy
+    inp = Inputs("be10dp")
+    for gain in (175000, 100_000_000_000):
+        cfg = copy.copy(inp.config)
+        cfg.det_params = copy.copy(inp.config.det_params)
+        cfg.det_params.mpgd_gain = gain
+        from attpc_engine_amd.engine import Engine
+        eng = Engine(inp.pipeline, cfg, inp.indices, context=ctx, chunk_events=700)
+        n = 1500
+        a = eng.run_spyral(n, seed=4, first_event=10)
+        ctx.set_option("compact_transfer", 0)
+        try:
+            b = eng.run_spyral(n, seed=4, first_event=10)
+        finally:
+            ctx.set_option("compact_transfer", 1)
+        np.testing.assert_array_equal(a["offsets"], b["offsets"])
+        np.testing.assert_array_equal(a["rows"], b["rows"])
+        np.testing.assert_array_equal(a["labels"], b["labels"])
+        np.testing.assert_array_equal(a["event_points"], b["event_points"])
+        assert a["offsets"][-1] > 1000
+        if gain > 175000:
+            assert a["rows"][:, 3].max() == 4095.0  # saturated amplitudes: these charges are far beyond 2^45
+    ctx._det_token = None
+
+
 def test_spyral_rows_golden(golden_dir, ctx):
     from attpc_engine_amd import GasTarget
     from attpc_engine_amd.detector.writer import convert_to_spyral

@@ -293,3 +293,29 @@ def test_pad_ids_outside_the_key_range_are_rejected(ctx):
     ctx._det_token = None
     with pytest.raises(ValueError, match="pad id"):
         ctx.check(ctx.lib.attpc_det_configure(ctx.handle, desc), "attpc_det_configure")
+
+
+def test_rows_too_large_for_the_transfer_record_go_the_plain_way(ctx, orc):
+    """Charges of 2^45 electrons and more do not fit the 16-byte transfer record (include/attpc_engine.h): such a
+    chunk is delivered in the reference's dtypes instead -- same rows either way.  (Also the u64 slow path of the
+    scatter for pixels above 2^28 electrons.)"""
+    cfg, raw, keep = _configure(ctx, 0.277)
+    xyt = np.array([[0.05, 0.04, 300.5], [0.051, 0.041, 300.7], [-0.1, 0.02, 120.2]])
+    el = np.array([5_000_000_000_000_000, 3_000_000, 9_000_000_000_000_000], dtype=np.int64)  # exact in f64
+    ev = [(xyt, el, 2)]
+    keys, charge, labels = orc.transport(raw, ev)
+    assert charge.max() >= (1 << 45)
+    tb, pad = np.array([orc.unpair(int(k)) for k in keys], dtype=np.int64).T
+    for compact in (1, 0):
+        ctx.set_option("compact_transfer", compact)
+        try:
+            (cloud,), stats = device_scatter(ctx, [ev])
+        finally:
+            ctx.set_option("compact_transfer", 1)
+        # the per-pixel truncation of products this large may differ in the last bits of a 2^52-sized number
+        keep_ref = (tb >= 0) & (tb < 512)
+        o_ref = np.lexsort((tb[keep_ref], pad[keep_ref]))
+        o_dev = np.lexsort((np.floor(cloud[0][:, 1]), cloud[0][:, 0]))
+        np.testing.assert_array_equal(cloud[0][o_dev, 0].astype(np.int64), pad[keep_ref][o_ref])
+        np.testing.assert_allclose(cloud[0][o_dev, 2], charge[keep_ref][o_ref].astype(np.float64), rtol=1e-12)
+        assert stats["n_failed"] == 0

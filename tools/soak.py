@@ -3,7 +3,7 @@ sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parents[1]
 from attpc_engine_amd import _abi, workloads
 from attpc_engine_amd.engine import Engine
 ctx = _abi.Context(0)
-for name, n, reps in (("o16aa", 500000, 6), ("be10dp", 500000, 4), ("b10chain", 60000, 3)):
+for name, n, reps in (("o16aa", 500000, 6), ("be10dp", 500000, 4), ("b10chain", 8000, 3)):
     pipe, cfg, idx = workloads.WORKLOADS[name]()
     eng = Engine(pipe, cfg, idx, context=ctx)
     ref = None

@@ -149,6 +149,8 @@ struct McEntry {
   uint32_t cs;         // entry number in the event (random-stream domain)
 };
 static_assert(sizeof(McEntry) * STAGE <= 2 * sizeof(short) * STAGE * MESH, "McEntry records overlay st_ix + st_iy");
+static_assert(2 * sizeof(short) * STAGE * MESH >= sizeof(uint32_t) * ATTPC_NUM_TB,
+              "st_ix + st_iy double as the per-bucket cursors of the entry sort (one u32 per time bucket)");
 
 struct __align__(16) ScatterShared {
   double wtab[PIXELS];        // first member: rows of 10 weights are read as five 16-byte pairs
@@ -423,7 +425,7 @@ __device__ __forceinline__ int fresh_tid() {
 // MC: the Monte-Carlo diffusion extension (its own instantiation, so that the default kernel keeps its
 // register budget)
 template <bool MC>
-__global__ __launch_bounds__(SC_THREADS, SC_THREADS / 256 * ATTPC_SC_WG_PER_CU) void scatter_kernel(ScatterArgs a) {
+__global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255) / 256) void scatter_kernel(ScatterArgs a) {
   __shared__ ScatterShared sh;
   // tid / lane are re-read through an opaque asm at every use (macros below): otherwise the compiler
   // hoists every tid-derived LDS address of every phase to the top of the kernel, runs out of the 128

@@ -94,6 +94,7 @@ struct attpc_ctx {
   bool opt_tiny = false;
   bool opt_compact = true;         // clouds cross PCIe as 16-byte records and are expanded by host threads
   int opt_unpack_threads = 0;      // 0: min(16, hardware threads)
+  int opt_deliver_chunk = 8192;    // events per chunk when clouds are delivered (the pipeline's fill and drain time)
 
   bool kin_ready = false;
   attpc_kin_desc kin{};            // device pointers inside
@@ -1014,7 +1015,7 @@ int32_t run_batch_chunks(attpc_ctx* ctx, const attpc_event_layout& lay, const Tr
     const bool pilot = ctx->rows_per_event <= 0.0;  // only ever true with nothing in flight
     // delivered clouds are PCIe bound: small chunks, so that the copy of one hides the scatter and
     // assembly of the next from the first chunk on
-    const uint32_t n = std::min<uint32_t>(next_chunk_events(ctx, nb - e0), 16384u);
+    const uint32_t n = std::min<uint32_t>(next_chunk_events(ctx, nb - e0), (uint32_t)ctx->opt_deliver_chunk);
     const Chunk c{e0, n, seq % MAX_SLOTS};
     const int set = seq & 1;
     // an overflow of the chunk in flight is repaired inside complete(); queue this one behind it
@@ -1219,6 +1220,9 @@ int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value) {
     ctx->opt_tiny = value != 0;
   } else if (key == "compact_transfer") {
     ctx->opt_compact = value != 0;
+  } else if (key == "deliver_chunk_events") {
+    if (value < 64 || value > (1 << 20)) return fail(ctx, ATTPC_E_INVALID, "deliver_chunk_events must be 64..1048576");
+    ctx->opt_deliver_chunk = (int)value;
   } else if (key == "unpack_threads") {
     if (value < 0 || value > 1024) return fail(ctx, ATTPC_E_INVALID, "unpack_threads must be 0..1024");
     ctx->opt_unpack_threads = (int)value;

@@ -217,6 +217,9 @@ ATTPC_API int32_t attpc_sync(attpc_ctx* ctx);
  *                      library-owned pinned staging and are expanded into the caller's arrays by host threads;
  *                      0: rows are copied in the reference's dtypes (32 bytes) straight into the caller's arrays
  *   "unpack_threads"   host threads of that expansion; 0 (default) = min(16, hardware threads)
+ *   "deliver_chunk_events"  events per chunk when clouds are delivered (default 8192: a chunk's copy hides the next
+ *                      chunk's scatter and assembly; the first chunk's device work and the last chunk's expansion
+ *                      stand alone, so smaller chunks shorten a short call)
  *   "chunk_events"     as attpc_set_chunk_events */
 ATTPC_API int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value);
 /* Page-locked host memory for output buffers (point clouds are PCIe bound on their way to the host:

@@ -154,8 +154,9 @@ static_assert(2 * sizeof(short) * STAGE * MESH >= sizeof(uint32_t) * ATTPC_NUM_T
 
 struct __align__(16) ScatterShared {
   double wtab[PIXELS];        // first member: rows of 10 weights are read as five 16-byte pairs
-  unsigned long long chg[HASH_CAP];  // electrons per key (ds_add_u64)
   uint32_t keys[HASH_CAP];    // bits 0..13 pad, 14..23 time bucket, 24..26 position in `indices`
+  unsigned long long chg[HASH_CAP];  // electrons per key (ds_add_u64); keys and chg sit below 64 KiB in both builds:
+                                     // stream_insert() addresses them through the 16-bit offset field
   uint2 queue[N_WAVES][WAVE_QUEUE + 2];  // per wave: (key|label, charge) of queued runs (+ dump slot);
                                          // the whole array is the slot list during a flush
   double st_n[STAGE];         // electrons x gain (x the slice weight of the longitudinal extension)
@@ -319,10 +320,12 @@ __device__ __forceinline__ bool wave_insert(ScatterShared& sh, uint32_t want, ui
 // lanes idle in the later ones, each trip a 1 KiB bucket read of the whole wave; here it is 1.33, every trip
 // but the last few of a round on (nearly) 64 runs.  (Tried and slower: linear probing with one returning
 // compare-and-swap per probe instead of the bucket read -- 2.3 trips per 64 runs, +12 % kernel time.)
+#ifdef ATTPC_SC_CXX_INSERT  // the compiler's version of the loop (A/B builds and diagnostic trip counts)
 struct InsertCarry {  // per lane
   uint32_t want, q;
   uint32_t b;         // bits 0..15 bucket, 16.. probes so far
   bool have;
+  __device__ __forceinline__ void reset() { want = 0u; q = 0u; b = 0u; have = false; }
 };
 
 __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __restrict__ queue, int n_q, bool drain,
@@ -376,6 +379,150 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
   }
   return !__any(fail);
 }
+#else
+// The shipped loop is written in gfx950 assembly.  hipcc's code for the C++ above spends ~75 vector + ~75 scalar
+// instructions and 13 branches per trip (per-lane flags that live across the loop are kept as 0/1 in vector
+// registers and turned into lane masks and back, every `if` becomes an exec-mask branch), and the trips were 59 % of
+// all instructions the kernel issued.  Here a trip is 45 vector + ~40 scalar instructions and 5 branches: `have` and
+// every condition are lane masks in scalar registers, the conditional LDS operations run under those masks, and the
+// per-lane probe count is replaced by a trip budget of the call (a table too full to take a run ends the window either
+// way).  Same table protocol as the C++ version: bucket read, ds_cmpst claim of the first free slot, ds_max label,
+// ds_add_u64 charge, a lost claim looks at the same bucket again.  Registers are named explicitly (the 128-bit bucket
+// and the {q, 0} pair of the 64-bit add need consecutive, even-aligned registers); the operands bind them.
+struct InsertCarry {
+  uint32_t want, q, ba;     // per lane: key | label, charge, byte offset of the bucket inside keys[]
+  unsigned long long have;  // wave uniform: lanes with a run under way
+  __device__ __forceinline__ void reset() { want = 0u; q = 0u; ba = 0u; have = 0ull; }
+};
+static_assert(offsetof(ScatterShared, keys) < 65536 && offsetof(ScatterShared, chg) < 65536,
+              "keys[] / chg[] are addressed as register + 16-bit offset field");
+
+__device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __restrict__ queue, int n_q, bool drain,
+                                              InsertCarry& c, unsigned int& claimed, unsigned int& trips) {
+  (void)sh; (void)trips;
+  uint32_t fail;
+  const uint32_t qbase = (uint32_t)(uintptr_t)queue;  // LDS byte address of the wave's queue
+  // wave-uniform values the compiler may hold in vector registers
+  c.have = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)c.have) |
+           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(c.have >> 32)) << 32);
+  claimed = (uint32_t)__builtin_amdgcn_readfirstlane(claimed);
+  asm volatile(
+      "s_mov_b32 s92, 0\n"              // next: first queue item nobody has taken yet
+      "v_mov_b32 v115, 0\n"             // v[114:115] = {q, 0}
+      "v_mov_b32 v126, -1\n"            // EMPTY
+      "s_mov_b32 s99, 0\n"              // fail
+      "v_mov_b32 v127, 0x9e3779b1\n"    // hash_bucket()'s multiplier
+      "s_mov_b64 s[70:71], exec\n"       // every lane of the wave (the callers are wave uniform)
+      "s_lshr_b32 s94, s93, 4\n"
+      "s_add_i32 s94, s94, 64\n"        // trip budget of this call
+      "1:\n"
+      "s_andn2_b64 s[72:73], exec, s[68:69]\n"  // idle lanes
+      "s_cmp_lt_i32 s92, s93\n"                 // fresh: this trip starts new runs
+      "s_cselect_b32 s96, 1, s98\n"             // go on = fresh | drain
+      "s_cbranch_scc0 2f\n"
+      "v_mbcnt_lo_u32_b32 v120, s72, 0\n"
+      "v_mbcnt_hi_u32_b32 v120, s73, v120\n"
+      "v_add_u32 v120, s92, v120\n"             // queue item of this idle lane
+      "v_cmp_gt_i32 vcc, s93, v120\n"
+      "s_and_b64 s[74:75], vcc, s[72:73]\n"     // lanes that take a new run
+      "s_bcnt1_i32_b64 s97, s[72:73]\n"
+      "s_add_i32 s92, s92, s97\n"
+      "s_min_i32 s92, s92, s93\n"
+      "s_or_b64 s[68:69], s[68:69], s[74:75]\n"
+      "s_mov_b64 exec, s[74:75]\n"
+      "v_lshl_add_u32 v120, v120, 3, v111\n"
+      "ds_read_b32 v112, v120\n"                // key | label
+      "ds_read_b32 v114, v120 offset:4\n"       // charge
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_and_b32 v121, 0xffffff, v112\n"
+      "v_mul_lo_u32 v113, v121, v127\n"
+      "v_lshrrev_b32 v113, %[shift], v113\n"
+      "v_and_b32 v113, %[bmask], v113\n"        // bucket * 16
+      "s_mov_b64 exec, s[70:71]\n"
+      "2:\n"
+      "s_cmp_eq_u64 s[68:69], 0\n"
+      "s_cbranch_scc1 9f\n"
+      "s_cmp_eq_u32 s96, 0\n"
+      "s_cbranch_scc1 9f\n"                     // queue used up: the unfinished runs ride along with the next block's
+      "s_add_i32 s94, s94, -1\n"
+      "s_cmp_eq_u32 s94, 0\n"
+      "s_cbranch_scc1 8f\n"
+      "s_mov_b64 exec, s[68:69]\n"
+      "ds_read_b128 v[116:119], v113 offset:%[keys]\n"
+      "v_and_b32 v121, 0xffffff, v112\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "v_and_b32 v120, 0xffffff, v116\n"
+      "v_cmp_eq_u32 s[76:77], v120, v121\n"
+      "v_and_b32 v120, 0xffffff, v117\n"
+      "v_cmp_eq_u32 s[78:79], v120, v121\n"
+      "v_and_b32 v120, 0xffffff, v118\n"
+      "v_cmp_eq_u32 s[80:81], v120, v121\n"
+      "v_and_b32 v120, 0xffffff, v119\n"
+      "v_cmp_eq_u32 vcc, v120, v121\n"
+      "v_cndmask_b32 v124, v119, v118, s[80:81]\n"   // the matching slot's word ...
+      "v_cndmask_b32 v124, v124, v117, s[78:79]\n"
+      "v_cndmask_b32 v124, v124, v116, s[76:77]\n"
+      "v_cndmask_b32 v122, 12, 8, s[80:81]\n"        // ... and its byte offset in the bucket
+      "v_cndmask_b32 v122, v122, 4, s[78:79]\n"
+      "v_cndmask_b32 v122, v122, 0, s[76:77]\n"
+      "s_or_b64 s[82:83], s[76:77], s[78:79]\n"
+      "s_or_b64 s[80:81], s[80:81], vcc\n"
+      "s_or_b64 s[82:83], s[82:83], s[80:81]\n"      // any slot holds the key
+      "v_cmp_eq_u32 s[76:77], -1, v116\n"
+      "v_cmp_eq_u32 s[78:79], -1, v117\n"
+      "v_cmp_eq_u32 s[80:81], -1, v118\n"
+      "v_cmp_eq_u32 vcc, -1, v119\n"
+      "v_cndmask_b32 v123, 12, 8, s[80:81]\n"        // first free slot
+      "v_cndmask_b32 v123, v123, 4, s[78:79]\n"
+      "v_cndmask_b32 v123, v123, 0, s[76:77]\n"
+      "s_or_b64 s[84:85], s[76:77], s[78:79]\n"
+      "s_or_b64 s[80:81], s[80:81], vcc\n"
+      "s_or_b64 s[84:85], s[84:85], s[80:81]\n"      // any slot free
+      "v_cndmask_b32 v122, v123, v122, s[82:83]\n"
+      "v_add_u32 v122, v113, v122\n"                 // byte offset of the slot inside keys[]
+      "s_andn2_b64 s[74:75], s[84:85], s[82:83]\n"   // claim: key not there, a slot free
+      "s_mov_b64 exec, s[74:75]\n"
+      "ds_cmpst_rtn_b32 v125, v122, v126, v112 offset:%[keys]\n"
+      "s_mov_b64 exec, s[68:69]\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "v_cmp_eq_u32 vcc, -1, v125\n"
+      "s_and_b64 s[86:87], vcc, s[74:75]\n"          // won the slot
+      "v_and_b32 v120, 0xffffff, v125\n"
+      "v_cmp_eq_u32 vcc, v120, v121\n"
+      "s_and_b64 s[88:89], vcc, s[74:75]\n"          // another lane claimed it for the same key
+      "s_bcnt1_i32_b64 s97, s[86:87]\n"
+      "s_add_i32 s95, s95, s97\n"                    // new keys of the wave
+      "s_or_b64 s[90:91], s[82:83], s[86:87]\n"
+      "s_or_b64 s[90:91], s[90:91], s[88:89]\n"      // done: the run's slot is known
+      "v_cndmask_b32 v124, v124, v125, s[88:89]\n"
+      "v_cmp_lt_u32 vcc, v124, v112\n"               // the slot's label is lower than this run's
+      "s_or_b64 s[76:77], s[82:83], s[88:89]\n"
+      "s_and_b64 exec, s[76:77], vcc\n"
+      "ds_max_u32 v122, v112 offset:%[keys]\n"
+      "s_mov_b64 exec, s[90:91]\n"
+      "v_lshlrev_b32 v120, 1, v122\n"
+      "ds_add_u64 v120, v[114:115] offset:%[chg]\n"
+      "s_or_b64 s[76:77], s[82:83], s[84:85]\n"
+      "s_andn2_b64 exec, s[68:69], s[76:77]\n"       // full bucket of other keys: on to the next one
+      "v_add_u32 v113, 16, v113\n"
+      "v_and_b32 v113, %[bmask], v113\n"
+      "s_mov_b64 exec, s[70:71]\n"
+      "s_andn2_b64 s[68:69], s[68:69], s[90:91]\n"   // a lost claim looks at the same bucket again
+      "s_branch 1b\n"
+      "8:\n"
+      "s_mov_b32 s99, 1\n"
+      "9:\n"
+      "s_mov_b64 exec, s[70:71]\n"
+      : "+{v112}"(c.want), "+{v113}"(c.ba), "+{v114}"(c.q), "+{s[68:69]}"(c.have), "+{s95}"(claimed), "={s99}"(fail)
+      : "{v111}"(qbase), "{s93}"(__builtin_amdgcn_readfirstlane(n_q)), "{s98}"((uint32_t)(drain ? 1u : 0u)),
+        [shift] "n"(32 - (HASH_BITS - 2) - 4), [bmask] "n"((N_BUCKETS - 1) * 16),
+        [keys] "n"(offsetof(ScatterShared, keys)), [chg] "n"(offsetof(ScatterShared, chg))
+      : "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s70", "s71",
+        "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
+        "s88", "s89", "s90", "s91", "s92", "s94", "s96", "s97", "vcc", "scc", "memory");
+  return fail == 0u;
+}
+#endif
 
 // Next window [win_a, win_b) of time buckets: starts at the first non-empty bucket >= `from` and
 // extends while the estimated key count stays within the budget (at least one bucket).  A window
@@ -642,7 +789,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           unsigned int claimed = 0u;  // new keys of this wave (wave uniform)
           unsigned int diag_trips = 0u, diag_calls = 0u;
           InsertCarry carry;
-          carry.want = 0u; carry.q = 0u; carry.b = 0u; carry.have = false;
+          carry.reset();
           bool ok = true;
 #ifdef ATTPC_SC_SKEW  // experiment: start half of the waves late, so that their LDS-bound insert phases meet the
                       // VALU-bound row phases of the others

@@ -101,7 +101,8 @@ namespace ATTPC_SC_CAT(sc_, ATTPC_SC_VARIANT) {
 constexpr int SC_THREADS = ATTPC_SC_THREADS;
 constexpr int N_WAVES = SC_THREADS / 64;
 constexpr int STAGE = ATTPC_SC_STAGE;            // entries staged per rows round
-constexpr int SORT_CAP = 1024;                   // events with at most this many entries are sorted by time bucket
+constexpr int SORT_CAP = 2048;                   // events with at most this many entries are sorted by time bucket
+constexpr int LDS_BLOCKS = SORT_CAP / ARENA_BLK; // arena block ids per track kept in LDS: all a sorted event can use
 constexpr int SORT_PER_THREAD = (SORT_CAP + SC_THREADS - 1) / SC_THREADS;
 constexpr int HASH_BITS = ATTPC_SC_HASH_BITS;
 constexpr int HASH_CAP = 1 << HASH_BITS;         // slots
@@ -163,7 +164,7 @@ struct __align__(16) ScatterShared {
   short st_ix[STAGE][MESH];   // the lane's coordinate: LUT index of the y mesh line i, lut_n = off the pad plane
   short st_iy[STAGE][MESH];   // the stepped coordinate: LUT index of the x mesh line j
   int st_tb[STAGE];           // bits 0..9 time bucket, 24..26 position in `indices`, 30 point transport
-  int blocks[ATTPC_MAX_SIM][MAX_BLOCKS_PER_TRACK];  // arena block ids of the event's tracks
+  int blocks[ATTPC_MAX_SIM][LDS_BLOCKS];  // the first arena block ids of the event's tracks (a sorted event has no others)
   long long label_of[ATTPC_MAX_SIM];  // row number (label) of each simulated nucleus
   int cnt[ATTPC_MAX_SIM + 1]; // exclusive prefix of kept samples per simulated nucleus
   unsigned long long cum[ATTPC_NUM_TB];  // inclusive prefix sums per time bucket: low word estimated keys,
@@ -180,17 +181,22 @@ struct __align__(16) ScatterShared {
   unsigned long long charge_sum, key_sum;
 };
 
-// sample c of the event's concatenated tracks -> record pointer and position in `indices`
-__device__ __forceinline__ const double* sample_ptr(const ScatterShared& sh, const double* arena, int n_sim, int c,
+// sample c of the event's concatenated tracks -> record pointer and position in `indices`.  `table` = the event's
+// rows of the block table in global memory: only events too long to be sorted (more than SORT_CAP entries) have
+// tracks with more than LDS_BLOCKS blocks, and only their code path passes it (nullptr: every block id is in LDS).
+__device__ __forceinline__ const double* sample_ptr(const ScatterShared& sh, const double* arena, const int32_t* table, int c,
                                                     int& isim) {
   isim = 0;
-  (void)n_sim;  // cnt[k] = total for k >= n_sim (per-event init), so c >= cnt[k] is false there: no k < n_sim test,
-                // which cost seven loop-invariant lane masks in scalar registers (spilled, reloaded per call)
+  // cnt[k] = total for k >= n_sim (per-event init), so c >= cnt[k] is false there: no k < n_sim test,
+  // which cost seven loop-invariant lane masks in scalar registers (spilled, reloaded per call)
 #pragma unroll
   for (int k = 1; k < ATTPC_MAX_SIM; ++k)
     if (c >= sh.cnt[k]) isim = k;
   const int s = c - sh.cnt[isim];
-  const int blk = sh.blocks[isim][s / ARENA_BLK];
+  const int bi = s / ARENA_BLK;
+  int blk;
+  if (table != nullptr && bi >= LDS_BLOCKS) blk = table[isim * MAX_BLOCKS_PER_TRACK + bi];
+  else blk = sh.blocks[isim][bi];
   return arena + ((size_t)blk * ARENA_BLK + (s & (ARENA_BLK - 1))) * 4;
 }
 
@@ -399,8 +405,8 @@ static_assert(offsetof(ScatterShared, keys) < 65536 && offsetof(ScatterShared, c
 
 __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __restrict__ queue, int n_q, bool drain,
                                               InsertCarry& c, unsigned int& claimed, unsigned int& trips) {
-  (void)sh; (void)trips;
-  uint32_t fail;
+  (void)sh;
+  uint32_t fail, budget_left;
   const uint32_t qbase = (uint32_t)(uintptr_t)queue;  // LDS byte address of the wave's queue
   // wave-uniform values the compiler may hold in vector registers
   c.have = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)c.have) |
@@ -513,13 +519,14 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
       "s_mov_b32 s99, 1\n"
       "9:\n"
       "s_mov_b64 exec, s[70:71]\n"
-      : "+{v112}"(c.want), "+{v113}"(c.ba), "+{v114}"(c.q), "+{s[68:69]}"(c.have), "+{s95}"(claimed), "={s99}"(fail)
+      : "+{v112}"(c.want), "+{v113}"(c.ba), "+{v114}"(c.q), "+{s[68:69]}"(c.have), "+{s95}"(claimed), "={s99}"(fail), "={s94}"(budget_left)
       : "{v111}"(qbase), "{s93}"(__builtin_amdgcn_readfirstlane(n_q)), "{s98}"((uint32_t)(drain ? 1u : 0u)),
         [shift] "n"(32 - (HASH_BITS - 2) - 4), [bmask] "n"((N_BUCKETS - 1) * 16),
         [keys] "n"(offsetof(ScatterShared, keys)), [chg] "n"(offsetof(ScatterShared, chg))
       : "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s70", "s71",
         "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
-        "s88", "s89", "s90", "s91", "s92", "s94", "s96", "s97", "vcc", "scc", "memory");
+        "s88", "s89", "s90", "s91", "s92", "s96", "s97", "vcc", "scc", "memory");
+  trips += ((uint32_t)n_q >> 4) + 64u - budget_left;  // diagnostic builds only (dead code otherwise)
   return fail == 0u;
 }
 #endif
@@ -643,9 +650,10 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
       }
       // the arena block ids of the event's tracks, loaded together with the counts (entries past a
       // track's last block are never used)
-      for (int i = tid; i < n_sim * MAX_BLOCKS_PER_TRACK; i += SC_THREADS) {
-        const int k = i / MAX_BLOCKS_PER_TRACK, b = i - k * MAX_BLOCKS_PER_TRACK;
-        sh.blocks[k][b] = a.trk.block_table[(size_t)(track0 + k) * MAX_BLOCKS_PER_TRACK + b];
+      const int32_t* __restrict__ ev_table = a.trk.block_table + (size_t)track0 * MAX_BLOCKS_PER_TRACK;
+      for (int i = tid; i < n_sim * LDS_BLOCKS; i += SC_THREADS) {
+        const int k = i / LDS_BLOCKS, b = i - k * LDS_BLOCKS;
+        sh.blocks[k][b] = ev_table[k * MAX_BLOCKS_PER_TRACK + b];
       }
       block_sync();
       const int total = sh.cnt[ATTPC_MAX_SIM];
@@ -666,7 +674,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           if (cs < total_s) {
             const int c = cs / n_slices;
             int isim;
-            const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
+            const double t = sample_ptr(sh, arena, nullptr, c, isim)[2];
             if (t >= 0.0) {
               const double ts = slice_time(a.det, t, cs - c * n_slices, n_slices);
               if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
@@ -679,7 +687,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
       } else {
         for (int c = tid; c < total; c += SC_THREADS) {
           int isim;
-          const double t = sample_ptr(sh, arena, n_sim, c, isim)[2];
+          const double t = sample_ptr(sh, arena, ev_table, c, isim)[2];
           if (!(t >= 0.0)) continue;
           const int est = key_estimate((int)fmin(t, 511.0), spread);
           for (int sl = 0; sl < n_slices; ++sl) {
@@ -959,7 +967,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
               const int cs = (int)sh.perm[r0 + base + tid];
               const int c = cs / n_slices;
               int isim;
-              const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
+              const double* rec = sample_ptr(sh, arena, nullptr, c, isim);
               stage_entry(tid, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1], isim,
                           cs - c * n_slices, cs);
             }
@@ -986,7 +994,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           if (c0 + tid < total_s) {  // the whole record in one round trip, in the window or not
             const int c = (c0 + tid) / n_slices;
             sl = (c0 + tid) - c * n_slices;
-            const double* rec = sample_ptr(sh, arena, n_sim, c, isim);
+            const double* rec = sample_ptr(sh, arena, ev_table, c, isim);
             xy = reinterpret_cast<const double2*>(rec)[0];
             tn = reinterpret_cast<const double2*>(rec)[1];
             const double ts = tn.x >= 0.0 ? slice_time(a.det, tn.x, sl, n_slices) : -1.0;
@@ -1034,7 +1042,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             if (rank - round_lo >= 0 && rank - round_lo < STAGE) {  // rest of this chunk: the records were not
               const int c = (c0 + tid) / n_slices;                   // kept in registers across the rows phase
               int isim2;
-              const double* rec = sample_ptr(sh, arena, n_sim, c, isim2);
+              const double* rec = sample_ptr(sh, arena, ev_table, c, isim2);
               stage_entry(rank - round_lo, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1],
                           isim2, (c0 + tid) - c * n_slices, c0 + tid);
             }

@@ -107,6 +107,14 @@ constexpr int SORT_PER_THREAD = (SORT_CAP + SC_THREADS - 1) / SC_THREADS;
 constexpr int HASH_BITS = ATTPC_SC_HASH_BITS;
 constexpr int HASH_CAP = 1 << HASH_BITS;         // slots
 constexpr int TARGET_KEYS = HASH_CAP * ATTPC_SC_TARGET_PCT / 100;  // aimed-at fill: inserts slow down steeply beyond ~55 %
+#ifndef ATTPC_SC_BUDGET_MAX_MULT
+#define ATTPC_SC_BUDGET_MAX_MULT 64
+#endif
+#ifndef ATTPC_SC_BUDGET_GROWTH
+#define ATTPC_SC_BUDGET_GROWTH 2
+#endif
+constexpr int BUDGET_GROWTH = ATTPC_SC_BUDGET_GROWTH;  // ... and the previous window's budget by this factor
+constexpr int BUDGET_MAX_MULT = ATTPC_SC_BUDGET_MAX_MULT;  // a window's estimated keys may exceed the aimed-at fill by this factor
 constexpr int WAVE_QUEUE = ATTPC_SC_WAVE_QUEUE;  // queued runs per wave and pass (typ. ~190 per 64 mesh rows)
 constexpr int MESH = ATTPC_MESH_STEPS;
 constexpr int PIXELS = MESH * MESH;
@@ -1161,9 +1169,15 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
         }
         if (tid < 64) {  // wave 0 chooses the next window; the barrier after the row stores publishes it
           // adapt the estimate to this event: observed keys per estimated key of the last window
-          const int ratio_x16 = sh.win_samples > 0 ? (int)(n_rows * 16u) / sh.win_samples : 16;
-          const int budget = ratio_x16 > 0 ? TARGET_KEYS * 16 / ratio_x16 : TARGET_KEYS;
-          select_window(sh, win_b, min(max(budget, TARGET_KEYS / 8), TARGET_KEYS * 4), lane);
+          // (the estimate counts every sample's pads anew; samples 0.1 mm apart share nearly all of theirs, so the
+          // factor reaches 1/40 with the path-length step at 10x diffusion: hence the wide upper bound)
+          const unsigned long long scaled =
+              n_rows ? (unsigned long long)TARGET_KEYS * (unsigned int)max(sh.win_samples, 1) / n_rows
+                     : (unsigned long long)TARGET_KEYS * BUDGET_MAX_MULT;
+          const unsigned long long top = min((unsigned long long)TARGET_KEYS * BUDGET_MAX_MULT,
+                                             (unsigned long long)max(sh.budget, TARGET_KEYS) * BUDGET_GROWTH);
+          const int budget = (int)min(max(scaled, (unsigned long long)(TARGET_KEYS / 8)), top);
+          select_window(sh, win_b, budget, lane);
           PHASE_MARK(18);
         }
         block_sync();

@@ -103,6 +103,8 @@ constexpr int N_WAVES = SC_THREADS / 64;
 constexpr int STAGE = ATTPC_SC_STAGE;            // entries staged per rows round
 constexpr int SORT_CAP = 2048;                   // events with at most this many entries are sorted by time bucket
 constexpr int LDS_BLOCKS = SORT_CAP / ARENA_BLK; // arena block ids per track kept in LDS: all a sorted event can use
+constexpr int MAX_CHUNKS = SORT_CAP / 4;         // chunks of an unsorted event with a time-bucket range of their own (the last
+                                                 // one stands for all further chunks)
 constexpr int SORT_PER_THREAD = (SORT_CAP + SC_THREADS - 1) / SC_THREADS;
 constexpr int HASH_BITS = ATTPC_SC_HASH_BITS;
 constexpr int HASH_CAP = 1 << HASH_BITS;         // slots
@@ -128,6 +130,7 @@ constexpr int CTRL_ROWS = 30;        // out.ctrl[]: rows actually written ([0] i
 constexpr int CTRL_MISMATCH = 31;    // out.ctrl[]: windows whose occupied-slot count differed from the claimed keys
 static_assert(STAGE <= SC_THREADS, "one lane per staged entry");
 static_assert(2 * N_WAVES * (WAVE_QUEUE + 2) >= HASH_CAP, "the wave queues double as the slot list of a flush");
+static_assert(2 * MAX_CHUNKS * sizeof(uint32_t) <= SORT_CAP * sizeof(unsigned short), "chunk ranges overlay perm[]");
 
 // Drift time of slice `sl` of a sample created at time bucket t: the sample itself without the
 // longitudinal-diffusion extension, else numpy.linspace(t - 3 sigma_l, t + 3 sigma_l, 5)[sl] with
@@ -178,7 +181,9 @@ struct __align__(16) ScatterShared {
   unsigned long long cum[ATTPC_NUM_TB];  // inclusive prefix sums per time bucket: low word estimated keys,
                                          // high word staged entries (samples x slices)
   unsigned long long wave_sum[SC_THREADS / 64];
-  unsigned short perm[SORT_CAP];    // entries (sample x slice) sorted by time bucket, events of <= SORT_CAP entries
+  unsigned short perm[SORT_CAP];    // entries (sample x slice) sorted by time bucket, events of <= SORT_CAP entries;
+                                    // longer events: lowest / highest time bucket of every chunk of SC_THREADS entries
+                                    // (two u32 per chunk: chunk_lo(), chunk_hi())
   int stage_sum[2][SC_THREADS / 64];  // in-window entries per wave of a staging chunk (double buffered)
   int win_a, win_b, win_samples, win_r0, win_n, budget, overflow, done, ev_failed, failed, retried;
   unsigned int wg_cursor, n_keys, batch_first;
@@ -539,6 +544,28 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
 }
 #endif
 
+// Time-bucket range of the chunks of an unsorted event (they overlay ScatterShared::perm, which such an event does not
+// use): lowest bucket of chunk k in word k, highest in word MAX_CHUNKS + k.
+__device__ __forceinline__ uint32_t* chunk_lo(ScatterShared& sh) { return reinterpret_cast<uint32_t*>(&sh.perm[0]); }
+__device__ __forceinline__ uint32_t* chunk_hi(ScatterShared& sh) { return reinterpret_cast<uint32_t*>(&sh.perm[0]) + MAX_CHUNKS; }
+__device__ __forceinline__ void chunk_range_add(ScatterShared& sh, int chunk, int tb) {
+  const int k = min(chunk, MAX_CHUNKS - 1);
+  atomicMin(chunk_lo(sh) + k, (uint32_t)tb);
+  atomicMax(chunk_hi(sh) + k, (uint32_t)tb);
+}
+// first chunk >= from (< n_chunks) whose range meets the window [win_a, win_b), n_chunks if there is none.  Every
+// wave computes it for itself (64 chunks per step); the ranges do not change while the windows are worked on.
+__device__ __forceinline__ int next_chunk_in_window(ScatterShared& sh, int from, int n_chunks, int win_a, int win_b, int ln) {
+  for (int k0 = from; k0 < n_chunks; k0 += 64) {
+    const int k = min(k0 + ln, MAX_CHUNKS - 1);
+    const bool hit = k0 + ln < n_chunks && (int)chunk_lo(sh)[k] < win_b && (int)chunk_hi(sh)[k] >= win_a &&
+                     chunk_lo(sh)[k] != 0xffffffffu;
+    const unsigned long long m = __ballot(hit);
+    if (m) return k0 + __ffsll((long long)m) - 1;
+  }
+  return n_chunks;
+}
+
 // Next window [win_a, win_b) of time buckets: starts at the first non-empty bucket >= `from` and
 // extends while the estimated key count stays within the budget (at least one bucket).  A window
 // that does not reach the end of the event is then cut back to a whole number of row passes: the
@@ -693,6 +720,15 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           }
         }
       } else {
+        // an event too long to be sorted: its windows scan the entry list in chunks of SC_THREADS; the time-bucket
+        // range of every chunk is recorded here, so that a window only looks at the chunks that can hold entries of
+        // its own (samples follow their track, a window's entries sit in a few stretches of the list: configs[4]
+        // has 39 chunks per event and ~27 windows, each of which now reads 3-4 chunks instead of all)
+        for (int i = tid; i < MAX_CHUNKS; i += SC_THREADS) {
+          chunk_lo(sh)[i] = 0xffffffffu;
+          chunk_hi(sh)[i] = 0u;
+        }
+        block_sync();
         for (int c = tid; c < total; c += SC_THREADS) {
           int isim;
           const double t = sample_ptr(sh, arena, ev_table, c, isim)[2];
@@ -700,7 +736,10 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           const int est = key_estimate((int)fmin(t, 511.0), spread);
           for (int sl = 0; sl < n_slices; ++sl) {
             const double ts = slice_time(a.det, t, sl, n_slices);
-            if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) atomicAdd(&sh.cum[(int)ts], (1ull << 32) | (unsigned long long)est);
+            if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
+              atomicAdd(&sh.cum[(int)ts], (1ull << 32) | (unsigned long long)est);
+              chunk_range_add(sh, (c * n_slices + sl) / SC_THREADS, (int)ts);
+            }
           }
         }
       }
@@ -995,7 +1034,12 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             if (sh.overflow) break;  // uniform: every thread sees the flag after the barrier
           }
         }
-        for (int c0 = 0, chunk = 0; !sorted && c0 < total_s && !stop; c0 += SC_THREADS, ++chunk) {
+        // (an unsorted event: only the chunks whose time-bucket range meets the window are read)
+        const int n_chunks = sorted ? 0 : (total_s + SC_THREADS - 1) / SC_THREADS;
+        int chunk_next = sorted ? 0 : next_chunk_in_window(sh, 0, n_chunks, win_a, win_b, lane);
+        for (int chunk = 0; chunk_next < n_chunks && !stop; ++chunk) {  // `chunk` counts the chunks read (buffer parity)
+          const int c0 = chunk_next * SC_THREADS;
+          chunk_next = next_chunk_in_window(sh, chunk_next + 1, n_chunks, win_a, win_b, lane);
           bool in_win = false;
           double2 xy = {0.0, 0.0}, tn = {0.0, 0.0};
           int isim = 0, sl = 0;
@@ -1020,7 +1064,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             rank += w < (tid >> 6) ? n_w : 0;
             filled_new += n_w;
           }
-          const bool last_chunk = c0 + SC_THREADS >= total_s;
+          const bool last_chunk = chunk_next >= n_chunks;  // no later chunk holds entries of this window
           if (rank - round_lo >= 0 && rank - round_lo < STAGE) stage_entry(rank - round_lo, xy, tn, isim, sl, c0 + tid);
           for (;;) {
             const int pending = filled_new - round_lo;  // staged entries, workgroup uniform

@@ -32,7 +32,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 CLOCK_HZ = 2.4e9       # peak engine clock (same guide); 256 CUs x 4 SIMDs, a wave64 VALU instruction issues over 4 cycles
-N_CUS, SIMDS_PER_CU = 256, 4
+N_CUS, SIMDS_PER_CU, N_XCDS = 256, 4, 8
 # LDS atomics: an LDS instruction of a wave64 is serviced 32 lanes per LDS cycle at best (two lane groups,
 # MI355X_MICROARCH.md "LDS"), one LDS pipeline per CU -> at most CLOCK / 2 wave-level atomics per CU and second
 LDS_ATOMIC_PEAK_PER_S = N_CUS * CLOCK_HZ / 2.0
@@ -218,9 +218,12 @@ def issue_roofs(workload: str, kernel: str, events_per_launch: float, avg_launch
         # wave64 VALU instruction = 4 issue cycles of one SIMD (16 lanes per cycle; f64 ones take longer, so
         # this is a lower bound of the busy share)
         out["valu_issue_frac"] = valu * 4.0 / (N_CUS * SIMDS_PER_CU * CLOCK_HZ * seconds)
-    if "SQ_ACTIVE_INST_VALU" in counters and "SQ_BUSY_CYCLES" in counters and counters["SQ_BUSY_CYCLES"] > 0:
-        out["valu_busy_frac_profiled"] = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / (counters["SQ_BUSY_CYCLES"] * SIMDS_PER_CU) \
-            if counters["SQ_BUSY_CYCLES"] else None
+    if "SQ_ACTIVE_INST_VALU" in counters and counters.get("GRBM_GUI_ACTIVE", 0) > 0:
+        # share of the profiled run's SIMD cycles with a VALU instruction under way: SQ_ACTIVE_INST_VALU counts
+        # quad-cycles summed over the chip's SIMDs, GRBM_GUI_ACTIVE the busy cycles of the launches summed over
+        # the 8 XCDs
+        simd_cycles = counters["GRBM_GUI_ACTIVE"] / N_XCDS * N_CUS * SIMDS_PER_CU
+        out["valu_busy_frac_profiled"] = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
     if "SQ_INSTS_LDS_ATOMIC" in counters:
         atomics = counters["SQ_INSTS_LDS_ATOMIC"] / events * events_per_launch
         out["lds_atomics_per_event"] = counters["SQ_INSTS_LDS_ATOMIC"] / events

@@ -172,7 +172,9 @@ def main() -> None:
     }
     if world_size == 1 and not args.no_delivered and config is not None:
         try:
-            line["delivered"] = delivered(engine, min(args.delivered_events, args.events), args.seed, bytes_per_event, p_event)
+            # (bounded by the rows as well: 60 000 events of configs[4] would be 100 GB of cloud)
+            n_deliver = min(args.delivered_events, args.events, max(1000, int(4.5e8 / max(p_event, 1.0))))
+            line["delivered"] = delivered(engine, n_deliver, args.seed, bytes_per_event, p_event)
         except Exception as exc:  # the headline line must not depend on this leg
             line["delivered"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world_size == 1 and not args.no_cpu_baseline:

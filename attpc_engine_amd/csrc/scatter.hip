@@ -12,7 +12,8 @@
 // a global counter; one event at a time, its dictionary is an open-addressing hash table in LDS
 // (u32 key|label word + u64 charge per slot, buckets of 4 keys).
 // Per event: the entries (samples x slices) are histogrammed by time bucket, prefix-summed and
-// sorted by time bucket once; events with more keys than the table should hold are cut into
+// sorted by time bucket once (up to SORT_CAP entries; longer events rank their entry list chunk by chunk
+// and remember every chunk's time-bucket range); events with more keys than the table should hold are cut into
 // time-bucket windows (a key contains its time bucket, so windows partition the key space) sized by
 // an estimated key count and cut back to a whole number of row passes.  Per window:
 //   stage  one lane per entry of the window: sigma_t and the whole-mm LUT indices of the entry's
@@ -24,10 +25,10 @@
 //          from a ballot prefix
 //   insert (same wave) the queued runs as a stream, one probe step per lane and trip: ds_read_b128 bucket
 //          probe, ds_cmpst_b32 to claim a slot, ds_max_u32 for the label, ds_add_u64 for the charge; a lane
-//          that is done takes the next run at once
+//          that is done takes the next run at once (the loop is written in gfx950 assembly, stream_insert())
 //   flush  occupied slots compacted per wave, rows written (with the Philox time-bucket jitter) to a
 //          range of the output block this workgroup reserved, slots reset on the way
-// Merging before inserting cuts hash inserts ~7x (100 pixels -> ~15 pads per sample) and the
+// Merging before inserting cuts hash inserts 2.5x (100 pixels -> ~40 runs on ~15 pads per sample) and the
 // queue turns the sparse "which lanes end a run" pattern into dense wave work.  Pixel charges
 // are whole numbers far below 2^53, so integer accumulation is exact and order independent.
 // "label = last nucleus in `indices` order that touched the key" (transporter.py:249) is the
@@ -843,6 +844,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           const unsigned int row_pitch = 2u * (unsigned int)(lut_n + 1);  // bytes per iy row
           unsigned int claimed = 0u;  // new keys of this wave (wave uniform)
           unsigned int diag_trips = 0u, diag_calls = 0u;
+          (void)diag_calls;  // diagnostic builds only
           InsertCarry carry;
           carry.reset();
           bool ok = true;

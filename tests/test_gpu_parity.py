@@ -8,6 +8,8 @@ Tolerances (north star: "within a stated FP tolerance"):
     (integer truncation of products whose last bits differ between glibc and device libm;
     largest difference ever observed: 1)
 """
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -793,3 +795,40 @@ def test_spyral_rows_golden(golden_dir, ctx):
     np.testing.assert_allclose(get_response(cfg), g["response"], rtol=1e-13)
     rows = convert_to_spyral(g["points"], 560, 10, 1.0, g["response"], cfg.pad_centers, cfg.pad_sizes, ctx=ctx)
     np.testing.assert_allclose(rows, g["rows"], rtol=1e-12)
+
+
+def test_assembly_insert_loop_equals_the_compiled_one():
+    """The table-insert loop of the scatter kernel is hand-written gfx950 assembly (scatter.hip, stream_insert);
+    the C++ loop it replaced stays in the source behind ATTPC_SC_CXX_INSERT.  A library built with that switch must
+    give the same clouds: point counts, charge and key checksums, retries aside (the C++ loop gives up after 48
+    probes of a lane, the assembly after a trip budget of the call: both only end a window that is too full)."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parents[1]
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available to build the comparison library")
+    variant = root / "attpc_engine_amd" / "_lib" / "libattpc_test_cxxinsert.so"
+    csrc = root / "attpc_engine_amd" / "csrc"
+    sources = [csrc / n for n in ("abi.hip", "kinematics.hip", "tracks.hip", "scatter.hip", "scatter_small.hip", "lone.hip", "spyral.hip")]
+    if not variant.exists() or any(s.stat().st_mtime > variant.stat().st_mtime for s in sources):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+                        "-DATTPC_SC_CXX_INSERT", f"-I{root / 'include'}", f"-I{csrc}", "-o", str(variant)] + [str(s) for s in sources],
+                       check=True, capture_output=True)
+    shipped = root / "attpc_engine_amd" / "_lib" / "libattpc_hip.so"
+    out = {}
+    for tag, lib in (("asm", shipped), ("cxx", variant)):
+        env = dict(os.environ, ATTPC_HIP_LIBRARY=str(lib))
+        proc = subprocess.run([sys.executable, str(root / "tools" / "ab_scatter.py"), "--child", "o16aa,be10dp", "12000"],
+                              env=env, capture_output=True, text=True, timeout=600)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        out[tag] = json.loads(proc.stdout.strip().splitlines()[-1])
+    for name in ("o16aa", "be10dp"):
+        a, b = out["asm"][name], out["cxx"][name]
+        for k in ("points", "samples", "charge", "keys", "failed", "inconsistent"):
+            assert a[k] == b[k], (name, k, a[k], b[k])
+        assert a["failed"] == 0 and a["inconsistent"] == 0

@@ -403,7 +403,7 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
 // The shipped loop is written in gfx950 assembly.  hipcc's code for the C++ above spends ~75 vector + ~75 scalar
 // instructions and 13 branches per trip (per-lane flags that live across the loop are kept as 0/1 in vector
 // registers and turned into lane masks and back, every `if` becomes an exec-mask branch), and the trips were 59 % of
-// all instructions the kernel issued.  Here a trip is 45 vector + ~40 scalar instructions and 5 branches: `have` and
+// all instructions the kernel issued.  Here a trip is 40 vector + ~35 scalar instructions and 4 branches: `have` and
 // every condition are lane masks in scalar registers, the conditional LDS operations run under those masks, and the
 // per-lane probe count is replaced by a trip budget of the call (a table too full to take a run ends the window either
 // way).  Same table protocol as the C++ version: bucket read, ds_cmpst claim of the first free slot, ds_max label,
@@ -435,11 +435,11 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
       "s_mov_b64 s[70:71], exec\n"       // every lane of the wave (the callers are wave uniform)
       "s_lshr_b32 s94, s93, 4\n"
       "s_add_i32 s94, s94, 64\n"        // trip budget of this call
+      "v_and_b32 v121, 0xffffff, v112\n"  // keys of the runs carried over from the last call
       "1:\n"
       "s_andn2_b64 s[72:73], exec, s[68:69]\n"  // idle lanes
       "s_cmp_lt_i32 s92, s93\n"                 // fresh: this trip starts new runs
-      "s_cselect_b32 s96, 1, s98\n"             // go on = fresh | drain
-      "s_cbranch_scc0 2f\n"
+      "s_cbranch_scc0 3f\n"
       "v_mbcnt_lo_u32_b32 v120, s72, 0\n"
       "v_mbcnt_hi_u32_b32 v120, s73, v120\n"
       "v_add_u32 v120, s92, v120\n"             // queue item of this idle lane
@@ -462,14 +462,10 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
       "2:\n"
       "s_cmp_eq_u64 s[68:69], 0\n"
       "s_cbranch_scc1 9f\n"
-      "s_cmp_eq_u32 s96, 0\n"
-      "s_cbranch_scc1 9f\n"                     // queue used up: the unfinished runs ride along with the next block's
-      "s_add_i32 s94, s94, -1\n"
-      "s_cmp_eq_u32 s94, 0\n"
-      "s_cbranch_scc1 8f\n"
+      "s_sub_u32 s94, s94, 1\n"
+      "s_cbranch_scc1 8f\n"                     // out of trips: the table is too full for this window
       "s_mov_b64 exec, s[68:69]\n"
       "ds_read_b128 v[116:119], v113 offset:%[keys]\n"
-      "v_and_b32 v121, 0xffffff, v112\n"
       "s_waitcnt lgkmcnt(0)\n"
       "v_and_b32 v120, 0xffffff, v116\n"
       "v_cmp_eq_u32 s[76:77], v120, v121\n"
@@ -479,10 +475,7 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
       "v_cmp_eq_u32 s[80:81], v120, v121\n"
       "v_and_b32 v120, 0xffffff, v119\n"
       "v_cmp_eq_u32 vcc, v120, v121\n"
-      "v_cndmask_b32 v124, v119, v118, s[80:81]\n"   // the matching slot's word ...
-      "v_cndmask_b32 v124, v124, v117, s[78:79]\n"
-      "v_cndmask_b32 v124, v124, v116, s[76:77]\n"
-      "v_cndmask_b32 v122, 12, 8, s[80:81]\n"        // ... and its byte offset in the bucket
+      "v_cndmask_b32 v122, 12, 8, s[80:81]\n"        // byte offset of the matching slot in the bucket
       "v_cndmask_b32 v122, v122, 4, s[78:79]\n"
       "v_cndmask_b32 v122, v122, 0, s[76:77]\n"
       "s_or_b64 s[82:83], s[76:77], s[78:79]\n"
@@ -512,13 +505,9 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
       "s_and_b64 s[88:89], vcc, s[74:75]\n"          // another lane claimed it for the same key
       "s_bcnt1_i32_b64 s97, s[86:87]\n"
       "s_add_i32 s95, s95, s97\n"                    // new keys of the wave
-      "s_or_b64 s[90:91], s[82:83], s[86:87]\n"
-      "s_or_b64 s[90:91], s[90:91], s[88:89]\n"      // done: the run's slot is known
-      "v_cndmask_b32 v124, v124, v125, s[88:89]\n"
-      "v_cmp_lt_u32 vcc, v124, v112\n"               // the slot's label is lower than this run's
-      "s_or_b64 s[76:77], s[82:83], s[88:89]\n"
-      "s_and_b64 exec, s[76:77], vcc\n"
-      "ds_max_u32 v122, v112 offset:%[keys]\n"
+      "s_or_b64 exec, s[82:83], s[88:89]\n"          // the slot was there already: raise its label
+      "ds_max_u32 v122, v112 offset:%[keys]\n"       // (a no-op where it is not lower; cheaper than finding out)
+      "s_or_b64 s[90:91], exec, s[86:87]\n"          // done: the run's slot is known
       "s_mov_b64 exec, s[90:91]\n"
       "v_lshlrev_b32 v120, 1, v122\n"
       "ds_add_u64 v120, v[114:115] offset:%[chg]\n"
@@ -529,6 +518,10 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
       "s_mov_b64 exec, s[70:71]\n"
       "s_andn2_b64 s[68:69], s[68:69], s[90:91]\n"   // a lost claim looks at the same bucket again
       "s_branch 1b\n"
+      "3:\n"                                         // the queue is used up
+      "s_cmp_eq_u32 s98, 0\n"
+      "s_cbranch_scc0 2b\n"                          // draining: go on with the runs under way
+      "s_branch 9f\n"                                // else they ride along with the next block's
       "8:\n"
       "s_mov_b32 s99, 1\n"
       "9:\n"
@@ -537,10 +530,10 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
       : "{v111}"(qbase), "{s93}"(__builtin_amdgcn_readfirstlane(n_q)), "{s98}"((uint32_t)(drain ? 1u : 0u)),
         [shift] "n"(32 - (HASH_BITS - 2) - 4), [bmask] "n"((N_BUCKETS - 1) * 16),
         [keys] "n"(offsetof(ScatterShared, keys)), [chg] "n"(offsetof(ScatterShared, chg))
-      : "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s70", "s71",
+      : "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v125", "v126", "v127", "s70", "s71",
         "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
-        "s88", "s89", "s90", "s91", "s92", "s96", "s97", "vcc", "scc", "memory");
-  trips += ((uint32_t)n_q >> 4) + 64u - budget_left;  // diagnostic builds only (dead code otherwise)
+        "s88", "s89", "s90", "s91", "s92", "s97", "vcc", "scc", "memory");
+  trips += ((uint32_t)n_q >> 4) + 64u - (fail ? 0u : budget_left);  // diagnostic builds only (dead code otherwise)
   return fail == 0u;
 }
 #endif

@@ -118,6 +118,8 @@ struct attpc_ctx {
   double blocks_per_track = 0.0;   // observed arena blocks per track
   bool prefer_big = false;         // sticky: the small scatter variant met too many lone buckets
   uint64_t n_growths = 0;          // device buffers (re)allocated so far (a steady workload stops growing)
+  uint32_t max_batch_events = 0;   // largest track batch so far: both track sets are sized for it (the set that
+                                   // first meets the shorter last batch of a call would otherwise grow in the next call)
 
   bool spyral_ready = false;
   SpyralDev spyral{};
@@ -390,6 +392,8 @@ __global__ __launch_bounds__(256) void count_status_kernel(const int32_t* __rest
 // ------------------------------------------------------------------ tracks ----
 int32_t ensure_kin_buffers(attpc_ctx* ctx, TrackSet& ts, uint32_t n, int n_rows) {
   int32_t rc;
+  ctx->max_batch_events = std::max(ctx->max_batch_events, n);
+  n = ctx->max_batch_events;
   if ((rc = ensure(ctx, ts.p4, (size_t)n * n_rows * 4 * sizeof(double)))) return rc;
   if ((rc = ensure(ctx, ts.vertex, (size_t)n * 3 * sizeof(double)))) return rc;
   if ((rc = ensure(ctx, ts.status, (size_t)n * sizeof(int32_t)))) return rc;
@@ -415,9 +419,11 @@ int32_t launch_tracks(attpc_ctx* ctx, TrackSet& ts, const TrackLaunch& tl) {
   if ((rc = ensure(ctx, ts.ctrl, 16 * sizeof(uint32_t)))) return rc;
   HIP_TRY(ctx, hipMemsetAsync(ts.ctrl.p, 0, 16 * sizeof(uint32_t), ctx->stream_t));
   if (n_tracks) {
-    if ((rc = ensure(ctx, ts.block_table, (size_t)n_tracks * MAX_BLOCKS_PER_TRACK * sizeof(int32_t)))) return rc;
-    if ((rc = ensure(ctx, ts.counts, (size_t)n_tracks * sizeof(int32_t)))) return rc;
-    if ((rc = ensure(ctx, ts.n_steps, (size_t)n_tracks * sizeof(int32_t)))) return rc;
+    ctx->max_batch_events = std::max(ctx->max_batch_events, tl.n);
+    const size_t alloc_tracks = (size_t)ctx->max_batch_events * (size_t)tl.lay.n_sim;
+    if ((rc = ensure(ctx, ts.block_table, alloc_tracks * MAX_BLOCKS_PER_TRACK * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ts.counts, alloc_tracks * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ts.n_steps, alloc_tracks * sizeof(int32_t)))) return rc;
     const size_t lds = (size_t)ctx->det.n_species * ATTPC_DEDX_NODES * sizeof(double);
     const uint32_t waves_needed = (n_tracks + 63) / 64;
     const uint32_t blocks = std::min<uint32_t>((waves_needed + 3) / 4, (uint32_t)ctx->n_cus * 8u);

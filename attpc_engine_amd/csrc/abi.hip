@@ -41,6 +41,7 @@ constexpr int MAX_SLOTS = 8;           // scatter chunks per track batch
 constexpr int CTRL_WORDS = 32;         // u64 control words per scatter launch (scatter.hip)
 constexpr uint32_t LONE_CAPACITY = 65536;
 constexpr int64_t CLOUD_BUDGET_BYTES = 24ll << 30;  // points + labels of one chunk
+constexpr int64_t DELIVER_CHUNK_ROWS = 96ll << 20;  // cloud rows of a chunk whose cloud is delivered (3 GB: ~60 ms of PCIe)
 constexpr uint64_t ARENA_BUDGET_BYTES = 24ull << 30;
 
 struct DevBuf {
@@ -118,6 +119,7 @@ struct attpc_ctx {
   double blocks_per_track = 0.0;   // observed arena blocks per track
   bool prefer_big = false;         // sticky: the small scatter variant met too many lone buckets
   uint64_t n_growths = 0;          // device buffers (re)allocated so far (a steady workload stops growing)
+  int64_t launch_row_cap = 0;      // row capacity given to the scatter launch queued last (<= cloud_capacity)
   uint32_t max_batch_events = 0;   // largest track batch so far: both track sets are sized for it (the set that
                                    // first meets the shorter last batch of a call would otherwise grow in the next call)
 
@@ -610,7 +612,11 @@ int32_t enqueue_scatter(attpc_ctx* ctx, int slot, const attpc_event_layout& lay,
   sa.out.lone_capacity = LONE_CAPACITY;
   sa.out.lone_chg = static_cast<unsigned long long*>(ctx->lone_chg.p);
   sa.out.lone_mask = static_cast<uint32_t*>(ctx->lone_mask.p);
-  sa.out.capacity = ctx->cloud_capacity;
+  // The launch may use what its plan asked for (or what a repeated launch was found to need), not the whole
+  // buffer: whoever assembles its cloud sizes the event-ordered copy, the Spyral rows and the transfer records by
+  // this number, and a device-resident run of large chunks may have left a buffer of many times that size.
+  ctx->launch_row_cap = std::min<int64_t>(ctx->cloud_capacity, std::max<int64_t>(p.grow_rows, min_rows));
+  sa.out.capacity = ctx->launch_row_cap;
   sa.out.seg_capacity = ctx->seg_capacity;
   sa.seed = seed;
   sa.first_event = first_event;
@@ -705,7 +711,7 @@ int32_t ensure_pinned_start(attpc_ctx* ctx, AsmSet& as, size_t len) {
 int32_t enqueue_assembly(attpc_ctx* ctx, int slot, AsmSet& as, uint32_t n, bool spyral) {
   int32_t rc;
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, as.copied, 0));  // the set's previous contents have left
-  const size_t cap = (size_t)ctx->cloud_capacity;
+  const size_t cap = (size_t)ctx->launch_row_cap;  // of the scatter launch queued just before (same stream, same slot)
   if ((rc = ensure(ctx, as.ev_start, ((size_t)n + 1) * sizeof(int64_t)))) return rc;
   if ((rc = ensure(ctx, as.points, cap * 3 * sizeof(double)))) return rc;
   if ((rc = ensure(ctx, as.labels, cap * sizeof(int64_t)))) return rc;
@@ -1021,7 +1027,11 @@ int32_t run_batch_chunks(attpc_ctx* ctx, const attpc_event_layout& lay, const Tr
     const bool pilot = ctx->rows_per_event <= 0.0;  // only ever true with nothing in flight
     // delivered clouds are PCIe bound: small chunks, so that the copy of one hides the scatter and
     // assembly of the next from the first chunk on
-    const uint32_t n = std::min<uint32_t>(next_chunk_events(ctx, nb - e0), (uint32_t)ctx->opt_deliver_chunk);
+    // ... and bounded in rows as well: the assembly sets, the Spyral sort scratch and the pinned staging all scale
+    // with the chunk's cloud (configs[4] has 54 k points per event: 8192 such events would be 100 GB of them)
+    uint32_t n = std::min<uint32_t>(next_chunk_events(ctx, nb - e0), (uint32_t)ctx->opt_deliver_chunk);
+    if (ctx->rows_per_event > 0.0)
+      n = std::min<uint32_t>(n, (uint32_t)std::max(256.0, (double)DELIVER_CHUNK_ROWS / ctx->rows_per_event));
     const Chunk c{e0, n, seq % MAX_SLOTS};
     const int set = seq & 1;
     // an overflow of the chunk in flight is repaired inside complete(); queue this one behind it

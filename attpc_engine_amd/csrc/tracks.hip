@@ -101,8 +101,8 @@ __global__ __launch_bounds__(TRACK_THREADS, ATTPC_TRACK_MIN_WAVES) void track_ke
   double g_ke = 0, g_zf = 0, g_zb = 0, g_rho = 0, ke_prev = 0;
   SpeciesConst sc = {0, 0, 0, 0};
   const double* tab = lds_tab;
-  double z_cache = 0.0;   // second Box-Muller normal of the cached Philox call
-  int z_cache_idx = -1;
+  double z_cache_cos = 0.0, z_cache_sin = 0.0;  // the two Box-Muller normals of the cached Philox pair ...
+  int z_cache_idx = -1;                         // ... and its index (sample >> 1)
   uint32_t ids_next = 0, ids_end = 0;    // this wave's batch of track ids (wave uniform)
   uint32_t pool_next = 0, pool_end = 0;  // this wave's reserved arena blocks (wave uniform)
 
@@ -182,8 +182,9 @@ __global__ __launch_bounds__(TRACK_THREADS, ATTPC_TRACK_MIN_WAVES) void track_ke
     if (__all(retired)) break;
 
     for (int it = 0; it < STEPS_PER_REFILL; ++it) {
-      bool stop = false;
+      bool stop = false, want_z = false;
       long long n_el = 0;
+      double mu_s = 0.0, sig_s = 0.0;
       if constexpr (PATH) {
         if (active) {
           // sample every path_step of arc length, never coarser than the reference grid; the speed is
@@ -235,23 +236,39 @@ __global__ __launch_bounds__(TRACK_THREADS, ATTPC_TRACK_MIN_WAVES) void track_ke
           const double mu = fabs(dc.ke - ke_prev) * e_scale;
           ke_prev = dc.ke;
           const double sig = sqrt(a.det.fano_factor * mu);
-          if (mu + 9.0 * sig >= 1.0) {  // |z| <= 8.6 for a 53-bit uniform: otherwise n = 0 for certain
-            double z;
-            if (z_cache_idx == (k >> 1) && (k & 1)) {
-              z = z_cache;
-            } else {
-              double ua, ub;
-              rng_pair(a.seed, event, (uint32_t)(k >> 1), fano_domain, ua, ub);
-              const double rad = sqrt(-2.0 * log(1.0 - ua));
-              double sn, cs;
-              sincos(TWO_PI * ub, &sn, &cs);
-              z = (k & 1) ? rad * sn : rad * cs;
-              z_cache = rad * sn;
-              z_cache_idx = k >> 1;
-            }
-            n_el = (long long)(mu + sig * z);
+          want_z = mu + 9.0 * sig >= 1.0;  // |z| <= 8.6 for a 53-bit uniform: otherwise n = 0 for certain
+          mu_s = mu;
+          sig_s = sig;
+        }
+      }
+      // The Fano draw: sample k uses the cosine (k even) or sine (k odd) normal of the Philox pair k >> 1, so a lane
+      // needs a new pair every other sample -- and the lanes of a wave are at different k.  When some lane needs a
+      // pair NOW, every other lane takes part as well: a lane whose cached pair serves its last sample now (k odd)
+      // computes its NEXT pair into the cache, a lane at an even k without the pair of k >> 1 computes that one
+      // (it may want the sine at k + 1).  The wave then runs the ~200 instructions of Philox + log + sincos every
+      // other step with all lanes in it instead of every step with half of them.  Same pairs, same normals.
+      {
+        const int idx_now = k >> 1;
+        const bool have_now = z_cache_idx == idx_now;
+        const bool need_now = want_z && !have_now;
+        double z = (k & 1) ? z_cache_sin : z_cache_cos;  // the cached normal (meaningful when have_now)
+        if (__any(need_now)) {
+          const bool sampled = active && !stop;  // k was advanced for this lane
+          const bool fill = sampled && (!have_now || (k & 1));
+          if (fill) {
+            const int idx = have_now ? idx_now + 1 : idx_now;
+            double ua, ub;
+            rng_pair(a.seed, event, (uint32_t)idx, fano_domain, ua, ub);
+            const double rad = sqrt(-2.0 * log(1.0 - ua));
+            double sn, cs;
+            sincos(TWO_PI * ub, &sn, &cs);
+            if (!have_now) z = (k & 1) ? rad * sn : rad * cs;
+            z_cache_cos = rad * cs;
+            z_cache_sin = rad * sn;
+            z_cache_idx = idx;
           }
         }
+        if (want_z) n_el = (long long)(mu_s + sig_s * z);
       }
       // arena blocks for the lanes that start a new block, from the wave's reserved pool (wave uniform:
       // one global atomic per BLOCK_POOL blocks instead of one per block)

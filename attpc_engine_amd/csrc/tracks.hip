@@ -71,7 +71,7 @@ __device__ __forceinline__ void rhs(const double s[6], const Decomp& d, const Sp
 }
 
 // PATH: the path-length sampling extension (DetDev::path_step > 0) -- its own instantiation, so that
-// the reference time-grid kernel keeps its register budget (167 VGPRs = 3 waves per SIMD) and its code.
+// the reference time-grid kernel keeps its registers (170 VGPRs, 2 waves per SIMD) and its code.
 #ifndef ATTPC_TRACK_MIN_WAVES
 #define ATTPC_TRACK_MIN_WAVES 1  // waves per SIMD the register allocation must leave room for (experiments)
 #endif

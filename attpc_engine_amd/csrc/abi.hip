@@ -59,6 +59,8 @@ struct TrackSet {  // kinematics + tracks of one track batch
 
 struct AsmSet {  // one chunk's cloud in event order, or its Spyral rows
   DevBuf ev_start, points, labels, kept, kept_start, sp_rows, sp_labels;
+  size_t row_cap = 0;  // rows the row-sized buffers of the set are kept at (grown with headroom: a launch's row
+                       // capacity follows the observed rows per event and moves by fractions of a percent)
   int64_t* h_start = nullptr;  // pinned [h_start_len]: CSR offsets of the chunk (n + 1 entries)
   size_t h_start_len = 0;
   uint32_t* h_ev_rows = nullptr;  // pinned [h_start_len]: cloud rows of every event before any threshold
@@ -711,7 +713,9 @@ int32_t ensure_pinned_start(attpc_ctx* ctx, AsmSet& as, size_t len) {
 int32_t enqueue_assembly(attpc_ctx* ctx, int slot, AsmSet& as, uint32_t n, bool spyral) {
   int32_t rc;
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, as.copied, 0));  // the set's previous contents have left
-  const size_t cap = (size_t)ctx->launch_row_cap;  // of the scatter launch queued just before (same stream, same slot)
+  // rows of the scatter launch queued just before (same stream, same slot), kept with 12 % headroom
+  if ((size_t)ctx->launch_row_cap > as.row_cap) as.row_cap = (size_t)ctx->launch_row_cap + (size_t)ctx->launch_row_cap / 8;
+  const size_t cap = as.row_cap;
   if ((rc = ensure(ctx, as.ev_start, ((size_t)n + 1) * sizeof(int64_t)))) return rc;
   if ((rc = ensure(ctx, as.points, cap * 3 * sizeof(double)))) return rc;
   if ((rc = ensure(ctx, as.labels, cap * sizeof(int64_t)))) return rc;

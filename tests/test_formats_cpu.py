@@ -187,3 +187,46 @@ def test_missing_h5py_warns_or_raises(tmp_path, monkeypatch):
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         KinematicsFileWriter(tmp_path / "kin3.npz", 1, [1], [1], 4)  # an explicit .npz needs no warning
+
+
+def test_convert_kinematics_table(tmp_path):
+    """The reference's convert-kinematics tool (convert_kinematics.py:11-63): one row per (event, nucleus),
+    event-major, columns event, Z, A, isotope, energy (= column 3 of the 4-vector), px, py, pz, vertex_x/y/z.
+    Written here from whole blocks of events with polars or pyarrow; the values and their order are checked against
+    the file's contents (the parquet bytes of polars themselves are parity unpinned: polars is not installable here)."""
+    import warnings
+
+    import pyarrow.parquet as pq
+
+    from attpc_engine_amd import nuclear_map
+    from attpc_engine_amd.io import KinematicsFileWriter
+    from attpc_engine_amd.kinematics.convert_kinematics import COLUMNS, convert_kinematics_hdf5_to_polars
+
+    rng = np.random.default_rng(7)
+    z, a = np.array([2, 8, 2, 8, 2, 6]), np.array([4, 16, 4, 16, 4, 12])
+    n = 37
+    vertex = rng.normal(size=(n, 3))
+    p4 = rng.normal(size=(n, len(z), 4))
+    path = tmp_path / "kine.npz"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        writer = KinematicsFileWriter(path, n, z, a, chunk_size=10)
+        writer.write_batch(0, vertex[:20], p4[:20])
+        writer.write_batch(20, vertex[20:], p4[20:])
+        writer.close()
+    out = tmp_path / "kine.parquet"
+    convert_kinematics_hdf5_to_polars(path, out)
+    table = pq.read_table(str(out))
+    assert tuple(table.column_names) == COLUMNS
+    assert table.num_rows == n * len(z)
+    cols = {name: table.column(name).to_numpy(zero_copy_only=False) for name in COLUMNS}
+    assert np.array_equal(cols["event"], np.repeat(np.arange(n), len(z)))
+    assert np.array_equal(cols["Z"], np.tile(z, n)) and np.array_equal(cols["A"], np.tile(a, n))
+    assert list(cols["isotope"][: len(z)]) == [nuclear_map.get_data(int(zz), int(aa)).isotopic_symbol for zz, aa in zip(z, a)]
+    flat = p4.reshape(-1, 4)
+    for name, col in (("px", 0), ("py", 1), ("pz", 2), ("energy", 3)):
+        assert np.array_equal(cols[name], flat[:, col]), name
+    for k, name in enumerate(("vertex_x", "vertex_y", "vertex_z")):
+        assert np.array_equal(cols[name], np.repeat(vertex[:, k], len(z))), name
+    with pytest.raises(Exception, match="does not exist"):
+        convert_kinematics_hdf5_to_polars(tmp_path / "missing.h5", out)

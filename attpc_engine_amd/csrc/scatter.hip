@@ -824,7 +824,10 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);
           return ok;
         };
-        auto rows_round = [&](int n_stage) -> bool {
+        // `carry`: the runs a lane has not finished (lost claim, full bucket) ride along from block to block -- and, in
+        // a sorted event, from round to round of a window: only the window's last round drains them (`drain`), so the
+        // sparse trips at the end of every round (a quarter of all trips) are not paid 7 times per event.
+        auto rows_round = [&](int n_stage, InsertCarry& carry, bool drain) -> bool {
           if constexpr (MC) return rows_round_mc(n_stage);
           const int n_rows = n_stage * MESH;
           const int wave = tid >> 6;
@@ -838,8 +841,6 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           unsigned int claimed = 0u;  // new keys of this wave (wave uniform)
           unsigned int diag_trips = 0u, diag_calls = 0u;
           (void)diag_calls;  // diagnostic builds only
-          InsertCarry carry;
-          carry.reset();
           bool ok = true;
 #ifdef ATTPC_SC_SKEW  // experiment: start half of the waves late, so that their LDS-bound insert phases meet the
                       // VALU-bound row phases of the others
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             ok = ok && !__any(!slow_ok);  // the slow path fails in single lanes
             if (!ok) break;    // table too full: the whole wave stops together
           }
-          if (ok) ok = stream_insert(sh, queue, 0, true, carry, claimed, diag_trips);  // the runs still under way
+          if (ok && drain) ok = stream_insert(sh, queue, 0, true, carry, claimed, diag_trips);  // the runs still under way
           if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);  // rows of the window's flush
           PHASE_COUNT(5, (unsigned long long)diag_trips + ((unsigned long long)diag_calls << 32));
           return ok;
@@ -1003,6 +1004,8 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
         };
         if (sorted) {  // the window is perm[win_r0 .. win_r0 + win_n): stage it densely, STAGE entries per round
           const int r0 = sh.win_r0, n_win = sh.win_n;
+          InsertCarry carry;
+          carry.reset();
           for (int base = 0; base < n_win; base += STAGE) {
             const int n_stage = min(STAGE, n_win - base);
             if (tid < n_stage) {
@@ -1018,7 +1021,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             PHASE_COUNT(12, 1);
             PHASE_COUNT(13, n_stage);
             PHASE_COUNT(14, (n_stage * MESH + SC_THREADS - 1) / SC_THREADS);
-            const bool ok = rows_round(n_stage);
+            const bool ok = rows_round(n_stage, carry, base + STAGE >= n_win);
             if (!ok) sh.overflow = 1;
             if (last_of_batch && !have_next && tid == 0) {
               next_first = take_batch();
@@ -1072,7 +1075,9 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             PHASE_COUNT(14, (n_stage * MESH + SC_THREADS - 1) / SC_THREADS);  // 64-row passes of the busiest wave
 
             // rows -> runs -> this wave's queue -> table, 64 mesh rows per wave at a time
-            const bool ok = rows_round(n_stage);
+            InsertCarry round_carry;
+            round_carry.reset();
+            const bool ok = rows_round(n_stage, round_carry, true);
             if (!ok) sh.overflow = 1;
             if (last_of_batch && !have_next && tid == 0) {
               next_first = take_batch();

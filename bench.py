@@ -7,10 +7,16 @@ One "step" = one pass of the hot path over one batch of E synthetic events per G
 (default: the BASELINE.json headline, 1e6-event two-step 16O(a,a')16O* -> a + 12C with the
 full pad-plane point cloud).  Inputs are generated on the device from Philox streams keyed
 by the global event id; the clouds stay resident in HBM (chunk buffers are overwritten),
-so `value` is device-resident whole-job throughput.  For N > 1 the driver starts this
-script once per GPU through torch.distributed.run; rank r simulates the event-id range
-[r*E, (r+1)*E) (weak scaling, no data-path collective); the timed region is bracketed by a
-barrier + device sync on both sides and the MAX over ranks is taken.
+so `value` is device-resident whole-job throughput.  N > 1 = one process per GPU: either the
+driver starts this script once per GPU through torch.distributed.run (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment), or -- `python bench.py --gpus N` with no such
+environment -- this process starts the N ranks itself, as fresh children and before it has
+touched a GPU, relays rank 0's JSON line and exits non-zero if any rank does.  A `--gpus`
+that disagrees with the world found in the environment is an error, never a silent 1-GPU run.
+Rank r simulates the event-id range [r*E, (r+1)*E) (weak scaling) or, with --global-events G
+(BASELINE configs[3]: 1e7 events over 8 GPUs), its contiguous share of G (strong scaling); no
+data-path collective; the timed region is bracketed by a barrier + device sync on both sides
+and the MAX over ranks is taken.
 
 The JSON line also carries
   roofline     -- algorithmic HBM bytes of the dominant kernel's launches / its measured
@@ -23,6 +29,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -39,44 +47,137 @@ LDS_ATOMIC_PEAK_PER_S = N_CUS * CLOCK_HZ / 2.0
 PMC_PROFILE = "r02_pmc.json"
 
 
-def main() -> None:
+def parse_args(argv=None) -> argparse.Namespace:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--events", type=int, default=1_000_000, help="events per GPU per step")
+    ap.add_argument("--events", type=int, default=1_000_000, help="events per GPU per step (weak scaling)")
+    ap.add_argument("--global-events", type=int, default=0,
+                    help="events per step over ALL GPUs, split into contiguous id ranges (strong scaling; "
+                         "BASELINE configs[3] = 10000000 with --gpus 8); overrides --events")
     ap.add_argument("--workload", default="o16aa")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--chunk-events", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-delivered", action="store_true", help="skip the delivered-to-host leg (clouds over PCIe)")
     ap.add_argument("--delivered-events", type=int, default=60_000)
-    args = ap.parse_args()
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="TEST ONLY: no GPU, no library -- a stand-in engine with made-up statistics, so that the "
+                         "launcher / sharding / reduction path runs on a CPU box; the line says data = 'stub'")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
 
-    from attpc_engine_amd import _abi, sharding, workloads
-    from attpc_engine_amd.engine import Engine
+
+def launch_ranks(args: argparse.Namespace, argv: list[str]) -> int:
+    """`python bench.py --gpus N` (N > 1) without a torchrun environment: start the N ranks as fresh child processes
+    of this script -- this parent has made no GPU call and makes none -- with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, pass rank 0's stdout (the JSON line) through, and return non-zero if any rank
+    failed.  A rank that dies takes the others down after a grace period instead of leaving them in a barrier."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = None
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = rc or code
+                deadline = deadline or time.monotonic() + 30.0  # the others may be waiting for it in a barrier
+        if deadline is not None and live and time.monotonic() > deadline:
+            for p in live:
+                p.kill()  # exactly the children started above
+        time.sleep(0.05)
+    if rc:
+        print(f"bench.py: a rank exited with status {rc}", file=sys.stderr)
+    return rc if 0 <= rc < 256 else 1
+
+
+class StubEngine:
+    """TEST ONLY (--stub-engine): stands where Engine stands, touches no GPU and no library; statistics are a pure
+    function of the event-id range, so that sums over ranks can be checked against one rank over the union."""
+
+    def __init__(self, n_rows: int):
+        self.n_rows = n_rows
+
+    def run(self, n_events: int, seed: int = 0, first_event: int = 0, **_kw) -> dict:
+        ids = range(first_event, first_event + n_events)
+        points = sum(100 + (i % 7) for i in ids)
+        time.sleep(0.01)
+        return {"stats": {"ms_kinematics": 0.0, "ms_tracks": 0.1, "ms_scatter": 1.0, "launches_kinematics": 0,
+                          "launches_tracks": 1, "launches_scatter": 1, "n_points": points, "n_track_samples": 10 * n_events,
+                          "n_failed": 0, "n_sample_limit": 0, "n_lone_buckets": 0, "n_inconsistent": 0,
+                          "n_buffer_growths": 0, "charge_checksum": (sum(ids) * 0x9E3779B97F4A7C15) % (1 << 64),
+                          "key_checksum": (sum(ids) * (2 * seed + 1)) % (1 << 64)}}
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)  # before anything that could touch a GPU (the imports below do not either)
+
+    from attpc_engine_amd import sharding, workloads
 
     rank, local_rank, world_size = sharding.world()
-    if args.gpus != world_size and world_size > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
-    dist = sharding.init_process_group("gloo")  # control plane only: barrier + scalar reductions
+    if args.gpus != world_size:
+        # never a silent n_gpus: 1 line for a --gpus N request, nor an N-rank job labelled as something else
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}", file=sys.stderr)
+        return 2
+    # control plane only: barrier + scalar reductions.  (gloo announces its connections on the C-level stdout:
+    # keep stdout for the one JSON line)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist = sharding.init_process_group("gloo")
+        sharding.barrier(dist)
+    finally:
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     pipeline, config, indices = workloads.WORKLOADS[args.workload](seed=args.seed)
-    n_dev = max(1, _abi.load_library().attpc_device_count())
-    ctx = _abi.Context(local_rank % n_dev)  # one rank per GPU; wraps only when rehearsing on fewer GPUs
-    engine = Engine(pipeline, config, indices, context=ctx, chunk_events=args.chunk_events or None)
-    first, n_events = sharding.weak_shard(args.events, rank)
+    if args.stub_engine:
+        ctx = None
+        engine = StubEngine(len(pipeline.get_proton_numbers()))
+    else:
+        from attpc_engine_amd import _abi
+        from attpc_engine_amd.engine import Engine
+
+        n_dev = max(1, _abi.load_library().attpc_device_count())
+        ctx = _abi.Context(local_rank % n_dev)  # one rank per GPU; wraps only when rehearsing on fewer GPUs
+        engine = Engine(pipeline, config, indices, context=ctx, chunk_events=args.chunk_events or None)
+    strong = args.global_events > 0
+    step_events = args.global_events if strong else args.events * world_size  # events of one step over all ranks
 
     def sync() -> None:
-        ctx.check(ctx.lib.attpc_sync(ctx.handle), "attpc_sync")
+        if ctx is not None:
+            ctx.check(ctx.lib.attpc_sync(ctx.handle), "attpc_sync")
 
-    # every step simulates its own range of global event ids (no replays): step s of rank r covers
-    # [(s * world_size + r) * E, ... + E); warm-up steps use the ranges after the timed ones
-    def step_first(step: int) -> int:
-        return step * args.events * world_size + first
+    # every step simulates its own range of global event ids (no replays): step s covers [s * G, (s + 1) * G) with
+    # G = events of a step over all ranks, of which rank r takes its contiguous share; warm-up steps use the
+    # ranges after the timed ones
+    def step_range(step: int) -> tuple[int, int]:
+        if strong:
+            return sharding.strong_shard(step_events, rank, world_size, first_event=step * step_events)
+        return sharding.weak_shard(args.events, rank, first_event=step * step_events)
 
     for w in range(args.warmup):
-        engine.run(n_events, seed=args.seed, first_event=step_first(args.steps + w))
+        first, n = step_range(args.steps + w)
+        engine.run(n, seed=args.seed, first_event=first)
     sync()
     sharding.barrier(dist)
     t0 = time.perf_counter()
@@ -86,8 +187,11 @@ def main() -> None:
     totals = {"n_points": 0, "n_track_samples": 0, "n_failed": 0, "n_sample_limit": 0, "n_lone_buckets": 0,
               "n_inconsistent": 0, "n_buffer_growths": 0}
     charge_acc = key_acc = 0
+    my_events = 0
     for step in range(args.steps):
-        stats = engine.run(n_events, seed=args.seed, first_event=step_first(step))["stats"]
+        first, n = step_range(step)
+        stats = engine.run(n, seed=args.seed, first_event=first)["stats"]
+        my_events += n
         for k in agg:
             agg[k] += stats[k]
         for k in totals:
@@ -98,24 +202,29 @@ def main() -> None:
     sharding.barrier(dist)
     elapsed = time.perf_counter() - t0
     (elapsed_max,) = sharding.reduce_scalars(dist, [elapsed], "max")
-    points, samples, failed, limit, lone = sharding.reduce_scalars(
+    points, samples, failed, limit, lone, events_all, ranks_seen = sharding.reduce_scalars(
         dist, [float(totals["n_points"]), float(totals["n_track_samples"]), float(totals["n_failed"]),
-               float(totals["n_sample_limit"]), float(totals["n_lone_buckets"])], "sum")
+               float(totals["n_sample_limit"]), float(totals["n_lone_buckets"]), float(my_events), 1.0], "sum")
     charge_sum, key_sum = sharding.reduce_checksums(dist, [charge_acc, key_acc])
+    if dist is not None:
+        dist.destroy_process_group()
     if rank != 0:
-        return
+        return 0
+    if int(ranks_seen) != world_size or int(events_all) != step_events * args.steps:
+        print(f"bench.py: {int(ranks_seen)} ranks / {int(events_all)} events seen, expected {world_size} / "
+              f"{step_events * args.steps}", file=sys.stderr)
+        return 3
 
-    total_events = args.events * world_size
-    value = total_events * args.steps / elapsed_max
+    value = step_events * args.steps / elapsed_max
     n_rows = len(pipeline.get_proton_numbers())
-    p_event = totals["n_points"] / max(1, n_events * args.steps)
+    p_event = totals["n_points"] / max(1, my_events)  # rank 0's events (every rank draws from the same distributions)
     # vertex f64[3] + p4 f64[N,4] + one i64 CSR offset + P points of 3 f64 + i64
     bytes_per_event = 24 + 32 * n_rows + 8 + 32 * p_event
     kernels = {"track_kernel": ("ms_tracks", "launches_tracks"), "scatter_kernel": ("ms_scatter", "launches_scatter")}
     dominant = max(kernels, key=lambda k: agg[kernels[k][0]])
     ms_key, launch_key = kernels[dominant]
     launches = max(1, agg[launch_key])
-    events_per_launch = n_events * args.steps / launches
+    events_per_launch = my_events / launches
     avg_ms = agg[ms_key] / launches
     achieved = events_per_launch * bytes_per_event / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic, traffic_note = measured_traffic(args.workload, dominant, events_per_launch)
@@ -129,19 +238,21 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": elapsed_max / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": "stub (TEST ONLY: no device work behind these numbers)" if args.stub_engine else "synthetic",
         "config": {
             "workload": f"{args.workload}: {workloads.describe(args.workload)}",
-            "events_per_gpu_per_step": args.events,
-            "global_events_per_step": total_events,
-            "parallelism": f"event-range shards x{world_size}, no collective in the data path",
+            "events_per_gpu_per_step": step_events / world_size,
+            "global_events_per_step": step_events,
+            "parallelism": f"contiguous event-id shards x{world_size} ({'even split of a fixed total' if strong else 'fixed work per GPU'}), "
+                           "one process per GPU, no collective in the data path",
+            "ranks_reporting": int(ranks_seen),
             "output": "device-resident point clouds (3 f64 + i64 per point), chunk buffers overwritten",
-            "points_per_event": p_event,
-            "track_samples_per_event": totals["n_track_samples"] / max(1, n_events * args.steps),
-            "event_ids": "step s, rank r: [(s*n_gpus + r)*E, +E) -- no step replays another",
+            "points_per_event": points / max(1.0, events_all),
+            "track_samples_per_event": samples / max(1.0, events_all),
+            "event_ids": "step s: [s*G, (s+1)*G), G = global events per step; rank r its contiguous share -- no step replays another",
             "algorithmic_bytes_per_event": bytes_per_event,
             "failed_events": failed,
             "lone_time_buckets": lone,
@@ -164,22 +275,26 @@ def main() -> None:
             "algorithmic_bytes_per_launch": events_per_launch * bytes_per_event,
             "avg_launch_ms": avg_ms,
             "events_per_launch": events_per_launch,
-            "kernel_ms_total": {k: agg[v[0]] for k, v in kernels.items()} | {"kin_run_kernel": agg["ms_kinematics"]},
+            "per": "GPU (rank 0's launches)",
+            # kin_run_kernel is left out: its HIP events sit on the low-priority stream and measure the wait for
+            # compute units behind the scatter workgroups, not the ~50 us the kernel runs (profiles/ kernel stats)
+            "kernel_ms_total": {k: agg[v[0]] for k, v in kernels.items()},
             "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md 4.3): frac is vs the HBM roof as the "
                     "contract asks, valu_issue_frac is the roof that binds",
             **issue,
         },
     }
-    if world_size == 1 and not args.no_delivered and config is not None:
+    if world_size == 1 and not args.no_delivered and config is not None and not args.stub_engine:
         try:
             # (bounded by the rows as well: 60 000 events of configs[4] would be 100 GB of cloud)
-            n_deliver = min(args.delivered_events, args.events, max(1000, int(4.5e8 / max(p_event, 1.0))))
+            n_deliver = min(args.delivered_events, step_events, max(1000, int(4.5e8 / max(p_event, 1.0))))
             line["delivered"] = delivered(engine, n_deliver, args.seed, bytes_per_event, p_event)
         except Exception as exc:  # the headline line must not depend on this leg
             line["delivered"] = {"error": f"{type(exc).__name__}: {exc}"}
-    if world_size == 1 and not args.no_cpu_baseline:
+    if world_size == 1 and not args.no_cpu_baseline and not args.stub_engine:
         line["cpu_baseline"] = cpu_baseline(args.workload, args.seed)
     print(json.dumps(line), flush=True)
+    return 0
 
 
 def _pmc(workload: str, kernel: str):
@@ -291,4 +406,4 @@ def cpu_baseline(workload: str, seed: int) -> dict:
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

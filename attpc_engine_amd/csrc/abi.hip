@@ -98,6 +98,7 @@ struct attpc_ctx {
   bool opt_compact = true;         // clouds cross PCIe as 16-byte records and are expanded by host threads
   int opt_unpack_threads = 0;      // 0: min(16, hardware threads)
   int opt_deliver_chunk = 8192;    // events per chunk when clouds are delivered (the pipeline's fill and drain time)
+  int opt_merge = -1;              // scatter kernel's merge variant: -1 automatic (path-length dE/dx step), 0 never, 1 always
 
   bool kin_ready = false;
   attpc_kin_desc kin{};            // device pointers inside
@@ -109,7 +110,7 @@ struct attpc_ctx {
 
   TrackSet tset[2];
   // cloud of one chunk
-  DevBuf points, labels, segments, ev_rows, lone_list, lone_chg, lone_mask, out_ctrl;
+  DevBuf points, labels, segments, ev_rows, lone_list, lone_chg, lone_mask, out_ctrl, merge_scratch;
   unsigned long long* h_out_ctrl = nullptr;  // pinned [MAX_SLOTS][CTRL_WORDS]
   hipEvent_t s0[MAX_SLOTS] = {}, s1[MAX_SLOTS] = {};
   int64_t cloud_capacity = 0, seg_capacity = 0;
@@ -586,9 +587,17 @@ int32_t enqueue_scatter(attpc_ctx* ctx, int slot, const attpc_event_layout& lay,
   int64_t want_rows = ctx->cloud_capacity, want_segs = ctx->seg_capacity;
   if (std::max(p.need_rows, min_rows) > ctx->cloud_capacity) want_rows = std::max(p.grow_rows, min_rows);
   if (std::max(p.need_segs, min_segs) > ctx->seg_capacity) want_segs = std::max(p.grow_segs, min_segs);
-  if (want_rows > ctx->cloud_capacity || want_segs > ctx->seg_capacity || (size_t)n * sizeof(uint32_t) > ctx->ev_rows.bytes) {
+  // merge variant (scatter.hip): track samples far closer than a pad, i.e. the path-length dE/dx step; every
+  // workgroup sorts its event's entries into two lists of its own in global memory
+  const bool merge = !ctx->det.mc_diffusion && (ctx->opt_merge == 1 || (ctx->opt_merge < 0 && ctx->det.path_step > 0.0));
+  const size_t merge_cap = (size_t)std::max(1, lay.n_sim) * MAX_BLOCKS_PER_TRACK * ARENA_BLK *
+                           (ctx->det.longitudinal_diffusion > 0.0 ? ATTPC_LONG_STEPS : 1);
+  const size_t merge_bytes = merge ? (size_t)p.wgs * 2 * merge_cap * sizeof(uint2) : 0;
+  if (want_rows > ctx->cloud_capacity || want_segs > ctx->seg_capacity || (size_t)n * sizeof(uint32_t) > ctx->ev_rows.bytes ||
+      merge_bytes > ctx->merge_scratch.bytes) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may use the old buffers
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
+    if ((rc = ensure(ctx, ctx->merge_scratch, merge_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->points, (size_t)want_rows * 3 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->labels, (size_t)want_rows * sizeof(int64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->segments, (size_t)want_segs * sizeof(Segment)))) return rc;
@@ -626,6 +635,8 @@ int32_t enqueue_scatter(attpc_ctx* ctx, int slot, const attpc_event_layout& lay,
   sa.event0 = e0;
   sa.batch = p.batch;
   sa.row_block = p.row_block;
+  sa.merge_scratch = merge ? static_cast<uint2*>(ctx->merge_scratch.p) : nullptr;
+  sa.merge_cap = (uint32_t)merge_cap;
   HIP_TRY(ctx, hipEventRecord(ctx->s0[slot], ctx->stream));
   if (p.use_small) launch_scatter_kernel_small(p.wgs, ctx->stream, sa);
   else launch_scatter_kernel_big(p.wgs, ctx->stream, sa);
@@ -1187,7 +1198,7 @@ int32_t attpc_ctx_destroy(attpc_ctx* ctx) {
   free_all(ctx->det_allocs);
   free_all(ctx->spyral_allocs);
   std::vector<DevBuf*> bufs = {&ctx->points, &ctx->labels, &ctx->segments, &ctx->ev_rows, &ctx->lone_list, &ctx->lone_chg,
-                               &ctx->lone_mask, &ctx->out_ctrl,
+                               &ctx->lone_mask, &ctx->out_ctrl, &ctx->merge_scratch,
                                &ctx->sort_idx, &ctx->sort_key};
   for (TrackSet& ts : ctx->tset) {
     for (DevBuf* b : {&ts.p4, &ts.vertex, &ts.status, &ts.attempts, &ts.arena, &ts.block_table, &ts.counts, &ts.n_steps, &ts.ctrl})
@@ -1246,6 +1257,9 @@ int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value) {
   } else if (key == "unpack_threads") {
     if (value < 0 || value > 1024) return fail(ctx, ATTPC_E_INVALID, "unpack_threads must be 0..1024");
     ctx->opt_unpack_threads = (int)value;
+  } else if (key == "scatter_merge") {
+    if (value < -1 || value > 1) return fail(ctx, ATTPC_E_INVALID, "scatter_merge must be -1, 0 or 1");
+    ctx->opt_merge = (int)value;
   } else if (key == "chunk_events") {
     return attpc_set_chunk_events(ctx, (int32_t)value);
   } else {

@@ -129,6 +129,15 @@ constexpr int CTRL_NEXT_EVENT = 28;  // out.ctrl[]: next unassigned event of the
 constexpr int CTRL_LONE = 29;        // out.ctrl[]: time buckets left to lone_bucket_kernel (entries of out.lone_list)
 constexpr int CTRL_ROWS = 30;        // out.ctrl[]: rows actually written ([0] is the reservation cursor)
 constexpr int CTRL_MISMATCH = 31;    // out.ctrl[]: windows whose occupied-slot count differed from the claimed keys
+// merge variant (scatter_kernel<false, true>): a wave works on MERGE_SEQ_PER_WAVE sequences of consecutive entries of
+// the window at a time, ten lanes (the mesh lines of constant y) per sequence; MERGE_G entries of every sequence are
+// staged per round
+constexpr int MERGE_SEQ_PER_WAVE = 64 / MESH;
+constexpr int MERGE_NSEQ = N_WAVES * MERGE_SEQ_PER_WAVE;
+constexpr int MERGE_G = STAGE / MERGE_NSEQ;
+constexpr int MERGE_ROUND = MERGE_NSEQ * MERGE_G;  // entries staged per round
+constexpr uint32_t MERGE_INVALID = 0xFFFFFFFFu;    // meta word of an entry outside 0 <= time bucket < 512
+static_assert(MERGE_G >= 1, "at least one staged entry per sequence and round");
 static_assert(STAGE <= SC_THREADS, "one lane per staged entry");
 static_assert(2 * N_WAVES * (WAVE_QUEUE + 2) >= HASH_CAP, "the wave queues double as the slot list of a flush");
 static_assert(2 * MAX_CHUNKS * sizeof(uint32_t) <= SORT_CAP * sizeof(unsigned short), "chunk ranges overlay perm[]");
@@ -525,6 +534,8 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
       "8:\n"
       "s_mov_b32 s99, 1\n"
       "9:\n"
+      "s_waitcnt lgkmcnt(0)\n"                       // (the budget exit can come straight after a fresh run's loads: the
+                                                     //  compiler does not track LDS reads issued in here)
       "s_mov_b64 exec, s[70:71]\n"
       : "+{v112}"(c.want), "+{v113}"(c.ba), "+{v114}"(c.q), "+{s[68:69]}"(c.have), "+{s95}"(claimed), "={s99}"(fail), "={s94}"(budget_left)
       : "{v111}"(qbase), "{s93}"(__builtin_amdgcn_readfirstlane(n_q)), "{s98}"((uint32_t)(drain ? 1u : 0u)),
@@ -537,6 +548,26 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
   return fail == 0u;
 }
 #endif
+
+// Merge variant: what a lane carries along its sequence of entries -- ten accumulators (the pad under each of the
+// ten pixels of its mesh line and the electrons gathered on it since the pad last changed) for one time bucket
+// and nucleus (`hi`, the high bits of the key word), and the fill of the wave's queue.
+constexpr uint32_t MERGE_NO_HI = 0xFFFFFFFFu;
+struct MergeAcc {
+  uint32_t hi;
+  int pad[MESH];     // -1: no accumulator for this pixel
+  uint32_t q[MESH];
+  int fill;          // wave uniform: runs waiting in the wave's queue
+  __device__ __forceinline__ void reset() {
+    hi = MERGE_NO_HI;
+    fill = 0;
+#pragma unroll
+    for (int j = 0; j < MESH; ++j) {
+      pad[j] = -1;
+      q[j] = 0u;
+    }
+  }
+};
 
 // Time-bucket range of the chunks of an unsorted event (they overlay ScatterShared::perm, which such an event does not
 // use): lowest bucket of chunk k in word k, highest in word MAX_CHUNKS + k.
@@ -565,6 +596,8 @@ __device__ __forceinline__ int next_chunk_in_window(ScatterShared& sh, int from,
 // that does not reach the end of the event is then cut back to a whole number of row passes: the
 // rows phase works in passes of SC_THREADS mesh rows (64 per wave), a window of 2.2 passes costs 3,
 // so the 0.2 is left to the next window.  Wave 0 (every lane with the same arguments).
+// `quantum` = entries of one full pass (SC_THREADS / MESH; merge variant: one staging round, MERGE_ROUND).
+template <int QUANTUM = SC_THREADS / MESH>
 __device__ __forceinline__ void select_window(ScatterShared& sh, int from, int budget, int ln) {
   const unsigned long long before = from > 0 ? sh.cum[from - 1] : 0ull;
   const unsigned int keys0 = (unsigned int)before, entries0 = (unsigned int)(before >> 32);
@@ -576,9 +609,10 @@ __device__ __forceinline__ void select_window(ScatterShared& sh, int from, int b
   int b0 = wave_upper_bound<false>(sh.cum, a0, ATTPC_NUM_TB, keys0 + (unsigned int)budget, ln);
   if (b0 <= a0) b0 = a0 + 1;
   const unsigned int entries = (unsigned int)(sh.cum[b0 - 1] >> 32) - entries0;
-  const unsigned int passes = entries * MESH / SC_THREADS;
+  const unsigned int passes = QUANTUM == SC_THREADS / MESH ? entries * MESH / SC_THREADS : entries / (unsigned int)QUANTUM;
   if (passes >= 1u && (unsigned int)(sh.cum[ATTPC_NUM_TB - 1] >> 32) > entries0 + entries) {
-    const int b1 = wave_upper_bound<true>(sh.cum, a0, b0, entries0 + passes * SC_THREADS / MESH, ln);
+    const int b1 = wave_upper_bound<true>(sh.cum, a0, b0,
+                                          entries0 + (QUANTUM == SC_THREADS / MESH ? passes * SC_THREADS / MESH : passes * (unsigned int)QUANTUM), ln);
     if (b1 > a0) b0 = b1;
   }
   if (ln == 0) {
@@ -606,8 +640,18 @@ __device__ __forceinline__ int fresh_tid() {
 }
 
 // MC: the Monte-Carlo diffusion extension (its own instantiation, so that the default kernel keeps its
-// register budget)
-template <bool MC>
+// register budget).
+// MERGE: the variant for track samples much closer than a pad (path-length dE/dx step, BASELINE configs[4]: samples
+// 0.1 mm apart, every one lighting ~100 pads at 10x diffusion -- scattered one by one that is 37 table inserts per key).
+// transporter.py:229-249 adds int(pdf h^2 n_k) to points[key] pixel by pixel; the sum over the samples k of a
+// track whose pixel (i, j) falls on the same pad in the same time bucket can be formed in a register before the
+// table sees it -- every term is still truncated on its own, so the result is the reference's exactly, in any
+// grouping.  The entries of an event are sorted by time bucket into a list in global memory with a counting sort
+// that keeps runs of consecutive samples together; a window of time buckets is cut into sequences of consecutive
+// list entries, ten lanes (mesh lines) per sequence; a lane walks along its sequence with ten accumulators
+// (pad, electrons) and emits a run to the wave's queue only when the pad under a pixel, the time bucket or the
+// nucleus changes.  Same windows, table, insert loop and flush as the default kernel; its own instantiation.
+template <bool MC, bool MERGE>
 __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255) / 256) void scatter_kernel(ScatterArgs a) {
   __shared__ ScatterShared sh;
   // tid / lane are re-read through an opaque asm at every use (macros below): otherwise the compiler
@@ -622,6 +666,10 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
   const double* __restrict__ arena = a.trk.arena;
   const float spread = (float)((6.0 / 4.9e-3) * (6.0 / 4.9e-3) * 2.0 * a.det.diffusion * a.det.dv / a.det.efield);
   const int n_slices = a.det.longitudinal_diffusion > 0.0 ? ATTPC_LONG_STEPS : 1;
+  constexpr int WQ = MERGE ? MERGE_ROUND : SC_THREADS / MESH;  // entries of one full pass (select_window)
+  // merge variant: this workgroup's two entry lists in global memory (list order / sorted by time bucket)
+  uint2* __restrict__ const mg_list = MERGE ? a.merge_scratch + (size_t)blockIdx.x * 2u * a.merge_cap : nullptr;
+  uint2* __restrict__ const mg_perm = MERGE ? mg_list + a.merge_cap : nullptr;
 
   PHASE_DECL;
   // ---- once per workgroup (persistent: it takes batches of events from a global counter) ----
@@ -692,11 +740,48 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
       const int total_s = total * n_slices;  // entries = samples x slices
       // t < 0 (sigma_t would be NaN: undefined in the reference) and tb >= 512 (removed by the
       // 0 <= tb < 512 mask of simulator.py:111-113) never reach the output
-      const bool sorted = total_s <= SORT_CAP;  // few enough entries: sort them by time bucket once
+      const bool sorted = MERGE || total_s <= SORT_CAP;  // few enough entries: sort them by time bucket once
       int my_tb[SORT_PER_THREAD];  // time bucket of this thread's entries tid, tid + SC_THREADS, ...
 #pragma unroll
       for (int k = 0; k < SORT_PER_THREAD; ++k) my_tb[k] = -1;
-      if (sorted) {
+      if constexpr (MERGE) {
+        // Entry e of the list = slice e / total of sample e % total (slice major: the samples of a track stay
+        // neighbours).  Every entry is resolved once -- arena record, time bucket, nucleus, slice -- and written to
+        // the list; later passes never touch the block table again.
+        for (int e0 = 0; e0 < total_s; e0 += 2 * SC_THREADS) {  // two entries per thread in flight
+          const double* rec[2];
+          int isim[2], sl[2];
+          double t[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int e = e0 + u * SC_THREADS + tid;
+            sl[u] = 0;
+            isim[u] = 0;
+            rec[u] = arena;
+            if (e < total_s) {
+              sl[u] = n_slices == 1 ? 0 : e / total;
+              rec[u] = sample_ptr(sh, arena, ev_table, e - sl[u] * total, isim[u]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) t[u] = rec[u][2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int e = e0 + u * SC_THREADS + tid;
+            if (e >= total_s) continue;
+            uint32_t meta = MERGE_INVALID;
+            if (t[u] >= 0.0) {
+              const double ts = slice_time(a.det, t[u], sl[u], n_slices);
+              if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
+                meta = (uint32_t)(int)ts | ((uint32_t)isim[u] << 10) | ((uint32_t)sl[u] << 13);
+                atomicAdd(&sh.cum[(int)ts], (1ull << 32) | (unsigned long long)key_estimate((int)fmin(t[u], 511.0), spread));
+              }
+            }
+            mg_list[e] = make_uint2((uint32_t)((rec[u] - arena) >> 2), meta);
+          }
+        }
+        __threadfence();  // the list is read back (by the same threads) in the sort pass below
+      } else if (sorted) {
 #pragma unroll
         for (int k = 0; k < SORT_PER_THREAD; ++k) {
           const int cs = tid + k * SC_THREADS;
@@ -764,6 +849,37 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
       }
       block_sync();
 
+      if constexpr (MERGE) {
+        // Counting sort by time bucket that keeps RUNS together: consecutive list entries of the same nucleus, slice
+        // and time bucket (the samples of a track while it stays inside one bucket) are placed as one block, by one
+        // returning LDS atomic of the run's first lane -- so the sorted list is, bucket by bucket, a sequence of
+        // stretches of track, and neighbours in it are neighbours in space.
+        uint32_t* __restrict__ cursors = reinterpret_cast<uint32_t*>(&sh.st_ix[0][0]);
+        for (int e0 = 0; e0 < total_s; e0 += SC_THREADS) {  // workgroup-uniform trip count (ballots inside)
+          const int e = e0 + tid;
+          unsigned long long raw = ~0ull;
+          if (e < total_s)
+            raw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(mg_list + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t meta = (uint32_t)(raw >> 32);
+          const bool valid = meta != MERGE_INVALID;
+          const uint32_t prev = (uint32_t)__shfl_up((int)meta, 1);
+          const bool head = valid && (lane == 0 || prev != meta);
+          const unsigned long long hm = __ballot(head), vm = __ballot(valid);
+          const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);  // lanes 0 .. lane
+          const unsigned long long mine = hm & upto;
+          const int h = mine ? 63 - __clzll((long long)mine) : 0;  // first lane of this lane's run
+          const unsigned long long breaks = (hm | ~vm) & ~upto;   // the run ends before the next head / invalid entry
+          const int next = breaks ? __ffsll((long long)breaks) - 1 : 64;
+          uint32_t pos = 0u;
+          if (head) {
+            const int tb = (int)(meta & 0x3ffu);
+            pos = (tb > 0 ? (uint32_t)(sh.cum[tb - 1] >> 32) : 0u) + atomicAdd(&cursors[tb], (uint32_t)(next - lane));
+          }
+          pos = (uint32_t)__shfl((int)pos, h);
+          if (valid) mg_perm[pos + (uint32_t)(lane - h)] = make_uint2((uint32_t)raw, meta);
+        }
+        __threadfence();  // read by other waves of the workgroup after the barrier below
+      }
 #pragma unroll
       for (int k = 0; k < SORT_PER_THREAD; ++k) {
         if (my_tb[k] >= 0) {  // counting sort: a window is then a contiguous range of perm[]
@@ -772,7 +888,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
               (unsigned short)(tid + k * SC_THREADS);
         }
       }
-      if (tid < 64) select_window(sh, 0, local_const(TARGET_KEYS), lane);
+      if (tid < 64) select_window<WQ>(sh, 0, local_const(TARGET_KEYS), lane);
       block_sync();
       PHASE_MARK(1);
 
@@ -969,6 +1085,141 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           return ok;
         };
 
+        // Merge variant of the rows phase.  Lane = mesh line i of sequence `sub` of its wave (lanes 60..63 idle); per
+        // round it steps through the MERGE_G staged entries of its sequence.  Per step: the line's ten pads (gathers)
+        // and pixel charges as in rows_round(); a pixel whose pad, time bucket and nucleus are those of the lane's
+        // accumulator adds to it, any other one first sends the accumulator to the wave's queue as a run.  The queue is
+        // handed to stream_insert() when it is nearly full, and drained at the window's last round (`last`).
+        auto rows_round_merge = [&](MergeAcc& m, InsertCarry& carry, bool last) -> bool {
+          const int wave = tid >> 6;
+          uint2* __restrict__ queue = sh.queue[wave];
+          const char* __restrict__ lut_bytes = reinterpret_cast<const char*>(lut);
+          const unsigned int row_pitch = 2u * (unsigned int)(lut_n + 1);
+          unsigned int claimed = 0u, diag_trips = 0u;
+          bool ok = true;
+          const int sub = lane / MESH;
+          const int i = lane - sub * MESH;
+          const bool lane_ok = sub < MERGE_SEQ_PER_WAVE;
+          const int slot0 = (wave * MERGE_SEQ_PER_WAVE + min(sub, MERGE_SEQ_PER_WAVE - 1)) * MERGE_G;
+          // the accumulators named in `ends` -> runs in the wave's queue
+          auto emit = [&](uint32_t ends) {
+            const uint32_t n_runs = (uint32_t)__popc(ends);
+            int first = 0, wave_total = 0;
+#pragma unroll
+            for (int bit = 0; bit < 4; ++bit) {
+              const unsigned long long mk = __ballot((n_runs >> bit) & 1u);
+              first += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u)) << bit;
+              wave_total += (int)__popcll(mk) << bit;
+            }
+            if (wave_total == 0) return;
+            if (m.fill + wave_total > WAVE_QUEUE) {  // no room: the queued runs go to the table first
+              ok = stream_insert(sh, queue, m.fill, false, carry, claimed, diag_trips);
+              m.fill = 0;
+              if (!ok) return;
+            }
+            if (wave_total <= WAVE_QUEUE) {
+              int e = m.fill + first;
+#pragma unroll
+              for (int j = 0; j < MESH; ++j) {
+                const bool put = (ends >> j) & 1u;
+                queue[put ? e : WAVE_QUEUE] = make_uint2(m.hi | (uint32_t)m.pad[j], m.q[j]);  // WAVE_QUEUE = dump slot
+                e += (int)((ends >> j) & 1u);
+              }
+              m.fill += wave_total;
+            } else {  // more runs than the queue holds (every lane changed bucket at once): in passes
+              for (int pass0 = 0; pass0 < wave_total && ok; pass0 += WAVE_QUEUE) {
+                int e = first - pass0;
+#pragma unroll
+                for (int j = 0; j < MESH; ++j) {
+                  const bool put = ((ends >> j) & 1u) && e >= 0 && e < WAVE_QUEUE;
+                  queue[put ? e : WAVE_QUEUE] = make_uint2(m.hi | (uint32_t)m.pad[j], m.q[j]);
+                  e += (int)((ends >> j) & 1u);
+                }
+                ok = stream_insert(sh, queue, min(wave_total - pass0, WAVE_QUEUE), false, carry, claimed, diag_trips);
+              }
+            }
+          };
+          for (int qs = 0; qs < MERGE_G && ok; ++qs) {  // wave-uniform trip count
+            const int st = slot0 + qs;
+            const int tbw = sh.st_tb[st];
+            const bool have = lane_ok && tbw >= 0;
+            const bool point = (tbw & (1 << 30)) != 0;
+            const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
+            const double n_el = sh.st_n[st];
+            const int ix = sh.st_ix[st][i];
+            const uint32_t* __restrict__ iy32 = reinterpret_cast<const uint32_t*>(&sh.st_iy[st][0]);
+            const double2* __restrict__ w2 = reinterpret_cast<const double2*>(&sh.wtab[i * MESH]);
+            unsigned int iy[MESH];
+            double w[MESH];
+#pragma unroll
+            for (int j = 0; j < MESH; j += 2) {
+              const uint32_t pair = iy32[j >> 1];
+              iy[j] = pair & 0xffffu;
+              iy[j + 1] = pair >> 16;
+              const double2 ww = w2[j >> 1];
+              w[j] = ww.x;
+              w[j + 1] = ww.y;
+            }
+            uint32_t el[MESH];
+#pragma unroll
+            for (int j = 0; j < MESH; ++j) el[j] = (uint32_t)(w[j] * n_el);  // cvt truncates (transporter.py:240-246)
+            const bool big = el[MESH / 2] >= (1u << 28);
+            const bool slow = have && ix != lut_n && (point || big);  // as in rows_round(): straight into the table
+            int pad[MESH];
+            {
+              const unsigned int col = 2u * (unsigned int)((have && !slow) ? ix : lut_n);
+#pragma unroll
+              for (int j = 0; j < MESH; ++j)
+                pad[j] = (int)*reinterpret_cast<const int16_t*>(lut_bytes + (__umul24(iy[j], row_pitch) + col));
+              asm volatile("" : "+v"(pad[0]), "+v"(pad[1]), "+v"(pad[2]), "+v"(pad[3]), "+v"(pad[4]), "+v"(pad[5]),
+                           "+v"(pad[6]), "+v"(pad[7]), "+v"(pad[8]), "+v"(pad[9]));
+            }
+            bool slow_ok = true;
+            if (__any(slow)) {
+              if (slow) {
+#pragma unroll 1
+                for (int j = 0; j < MESH && slow_ok; ++j) {
+                  if (point && (i != 0 || j != 0)) continue;
+                  const int p = (int)*reinterpret_cast<const int16_t*>(
+                      lut_bytes + (__umul24(iy[j], row_pitch) + 2u * (unsigned int)ix));
+                  const double q = (point ? 1.0 : sh.wtab[i * MESH + j]) * n_el;
+                  if (p >= 0) slow_ok = table_add(sh, word_hi | (uint32_t)p, (unsigned long long)q);
+                }
+              }
+            }
+            // which accumulators end here: another time bucket / nucleus ends all ten, another pad ends one; an
+            // accumulator near 2^31 is ended as well (a pixel adds less than 2^28), so the u32 sums cannot wrap
+            const bool restart = have && word_hi != m.hi;
+            uint32_t ends = 0u, changed = 0u;
+#pragma unroll
+            for (int j = 0; j < MESH; ++j) {
+              const bool chg = have && (restart || pad[j] != m.pad[j] || m.q[j] >= 0x80000000u);
+              changed |= chg ? (1u << j) : 0u;
+              ends |= (chg && m.pad[j] >= 0) ? (1u << j) : 0u;
+            }
+            emit(ends);
+#pragma unroll
+            for (int j = 0; j < MESH; ++j) {
+              const bool chg = (changed >> j) & 1u;
+              m.pad[j] = chg ? pad[j] : m.pad[j];
+              m.q[j] = (chg ? 0u : m.q[j]) + ((have && pad[j] >= 0) ? el[j] : 0u);
+            }
+            m.hi = have ? word_hi : m.hi;
+            ok = ok && !__any(!slow_ok);
+          }
+          if (last && ok) {  // the window ends: every accumulator becomes a run, the queue and the runs under way drain
+            uint32_t ends = 0u;
+#pragma unroll
+            for (int j = 0; j < MESH; ++j) ends |= m.pad[j] >= 0 ? (1u << j) : 0u;
+            emit(ends);
+            if (ok) ok = stream_insert(sh, queue, m.fill, true, carry, claimed, diag_trips);
+            m.fill = 0;
+          }
+          if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);  // rows of the window's flush
+          PHASE_COUNT(5, (unsigned long long)diag_trips);
+          return ok;
+        };
+
         // one (sample, slice) entry -> staging slot: sigma_t and the LUT indices of its 20 mesh lines
         auto stage_entry = [&](int slot, double2 xy, double2 tn, int isim, int sl, int cs) {
           const int tb = (int)slice_time(a.det, tn.x, sl, n_slices);  // transporter.py:238
@@ -1002,7 +1253,54 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           sh.st_n[slot] = (n_slices == 1 ? 1.0 : a.det.long_weights[sl]) * tn.y;  // x 1.0 is exact
           sh.st_tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
         };
-        if (sorted) {  // the window is perm[win_r0 .. win_r0 + win_n): stage it densely, STAGE entries per round
+        if constexpr (MERGE) {
+          // The window is mg_perm[win_r0 .. win_r0 + win_n), cut into MERGE_NSEQ sequences of L consecutive entries;
+          // round r stages entries r * MERGE_G .. of every sequence (slot = sequence * MERGE_G + k), so that a lane
+          // meets the entries of its sequence in list order, round after round, with its accumulators in registers.
+          const int r0 = sh.win_r0, n_win = sh.win_n;
+          const int n_rounds = (n_win + MERGE_ROUND - 1) / MERGE_ROUND;
+          const int seq_len = n_rounds * MERGE_G;
+          MergeAcc acc;
+          acc.reset();
+          InsertCarry carry;
+          carry.reset();
+          for (int r = 0; r < n_rounds; ++r) {
+            if (tid < MERGE_ROUND) {
+              const int sq = tid / MERGE_G;
+              const int rho = sq * seq_len + r * MERGE_G + (tid - sq * MERGE_G);
+              if (rho < n_win) {
+                const unsigned long long raw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(mg_perm + r0 + rho),
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double* rec = arena + (size_t)(uint32_t)raw * 4u;
+                const uint32_t meta = (uint32_t)(raw >> 32);
+                stage_entry(tid, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1],
+                            (int)((meta >> 10) & 7u), (int)((meta >> 13) & 7u), 0);
+              } else {
+                // no entry: the lanes of this slot skip the step -- their gathers still run, so the slot's indices
+                // must point into the table ("off the pad plane"), not at whatever the LDS held
+                sh.st_tb[tid] = -1;
+                sh.st_n[tid] = 0.0;
+#pragma unroll
+                for (int k = 0; k < MESH; ++k) {
+                  sh.st_ix[tid][k] = (short)lut_n;
+                  sh.st_iy[tid][k] = (short)lut_n;
+                }
+              }
+            }
+            block_sync();
+            PHASE_MARK(3);
+            PHASE_COUNT(12, 1);
+            const bool ok = rows_round_merge(acc, carry, r + 1 == n_rounds);
+            if (!ok) sh.overflow = 1;
+            if (last_of_batch && !have_next && tid == 0) {
+              next_first = take_batch();
+              have_next = true;
+            }
+            block_sync();
+            PHASE_MARK(4);
+            if (sh.overflow) break;  // uniform: every thread sees the flag after the barrier
+          }
+        } else if (sorted) {  // the window is perm[win_r0 .. win_r0 + win_n): stage it densely, STAGE entries per round
           const int r0 = sh.win_r0, n_win = sh.win_n;
           InsertCarry carry;
           carry.reset();
@@ -1125,7 +1423,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
               sh.overflow = 0;
               sh.n_keys = 0u;
             }
-            select_window(sh, lone ? win_a + 1 : win_a, budget, lane);
+            select_window<WQ>(sh, lone ? win_a + 1 : win_a, budget, lane);
           }
           block_sync();
           continue;
@@ -1221,7 +1519,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           const unsigned long long top = min((unsigned long long)TARGET_KEYS * BUDGET_MAX_MULT,
                                              (unsigned long long)max(sh.budget, TARGET_KEYS) * BUDGET_GROWTH);
           const int budget = (int)min(max(scaled, (unsigned long long)(TARGET_KEYS / 8)), top);
-          select_window(sh, win_b, budget, lane);
+          select_window<WQ>(sh, win_b, budget, lane);
           PHASE_MARK(18);
         }
         block_sync();
@@ -1307,9 +1605,11 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
 void ATTPC_SC_CAT(launch_scatter_kernel_, ATTPC_SC_VARIANT)(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a) {
   using namespace ATTPC_SC_CAT(sc_, ATTPC_SC_VARIANT);
   if (a.det.mc_diffusion)
-    hipLaunchKernelGGL(scatter_kernel<true>, dim3(n_workgroups), dim3(SC_THREADS), 0, s, a);
+    hipLaunchKernelGGL((scatter_kernel<true, false>), dim3(n_workgroups), dim3(SC_THREADS), 0, s, a);
+  else if (a.merge_scratch != nullptr)
+    hipLaunchKernelGGL((scatter_kernel<false, true>), dim3(n_workgroups), dim3(SC_THREADS), 0, s, a);
   else
-    hipLaunchKernelGGL(scatter_kernel<false>, dim3(n_workgroups), dim3(SC_THREADS), 0, s, a);
+    hipLaunchKernelGGL((scatter_kernel<false, false>), dim3(n_workgroups), dim3(SC_THREADS), 0, s, a);
 }
 
 }  // namespace attpc

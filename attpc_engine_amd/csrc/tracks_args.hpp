@@ -28,6 +28,11 @@ struct ScatterArgs {
   uint32_t event0;     // first event of this launch within the track batch (track ids start at event0 * n_sim)
   uint32_t batch;      // events a workgroup takes per visit to the event counter
   uint32_t row_block;  // output rows a workgroup reserves at a time (1: exactly what each window needs)
+  // merge variant of the kernel (scatter.hip, scatter_kernel<false, true>; path-length dE/dx step): per workgroup two
+  // lists of merge_cap 8-byte entries {arena record, time bucket | nucleus << 10 | slice << 13}, the event's entries
+  // in list order and sorted by time bucket; merge_cap >= the entries an event can have.  nullptr: the default kernel
+  uint2* merge_scratch;
+  uint32_t merge_cap;
 };
 
 void launch_kin_run(hipStream_t s, const attpc_kin_desc& d, uint64_t seed, uint64_t first_event, uint32_t n,

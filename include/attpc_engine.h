@@ -220,6 +220,10 @@ ATTPC_API int32_t attpc_sync(attpc_ctx* ctx);
  *   "deliver_chunk_events"  events per chunk when clouds are delivered (default 8192: a chunk's copy hides the next
  *                      chunk's scatter and assembly; the first chunk's device work and the last chunk's expansion
  *                      stand alone, so smaller chunks shorten a short call)
+ *   "scatter_merge"    -1 (default) = automatic, 0 = never, 1 = always use the scatter kernel's merge variant, which adds
+ *                      up the pixel charges of consecutive track samples that fall on the same pad in the same time
+ *                      bucket before the table sees them (same results; automatic = with the path-length dE/dx step,
+ *                      attpc_det_desc.path_step > 0, where samples are far closer than a pad)
  *   "chunk_events"     as attpc_set_chunk_events */
 ATTPC_API int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value);
 /* Page-locked host memory for output buffers (point clouds are PCIe bound on their way to the host:

@@ -30,6 +30,15 @@ def orc():
     return pyoracle
 
 
+def _rebuild(inp):
+    """Descriptors of `inp` again after its config was edited in place."""
+    from attpc_engine_amd.detector.luts import build_det_desc
+    nuclei = [nuclear_map.get_data(z, a) for z, a in inp.species]
+    inp.det, inp._k2 = build_det_desc(inp.config, nuclei, 1, fold_beam=True)
+    inp.det_raw, inp._k3 = build_det_desc(inp.config, nuclei, 1, fold_beam=False)
+    return inp
+
+
 def _engine(inp, ctx, **kw):
     from attpc_engine_amd.engine import Engine
     return Engine(inp.pipeline, inp.config, inp.indices, context=ctx, **kw)
@@ -495,6 +504,64 @@ def test_kernel_variants_agree():
         assert a["n_failed"] == 0 and a["n_inconsistent"] == 0
     print("lone buckets (big / small, b10chain):", stats["big", "b10chain"]["n_lone_buckets"],
           stats["small", "b10chain"]["n_lone_buckets"])
+
+
+@pytest.mark.parametrize("name,n,kw,det_kw", [
+    ("b10chain", 5, {}, {}),                                  # configs[4] as written (merge is its default there)
+    ("o16aa", 16, {"path_step": 1.0e-4}, {}),                 # path step at the default diffusion: short runs per pad
+    ("o16aa", 16, {}, {}),                                    # the reference's time grid through the merge variant
+    ("be10dp", 12, {}, {"longitudinal_diffusion": 0.1}),      # entries = samples x 5 slices, slice-major list order
+    ("be10dp", 12, {}, {"diffusion": 0.0}),                   # point transport (sigma = 0) goes straight to the table
+    ("o16aa", 12, {}, {"diffusion": 1.0e-4}),                 # all 100 pixels of a sample on one or two pads
+])
+def test_merge_variant_vs_oracle(orc, name, n, kw, det_kw):
+    """scatter_kernel<false, true> (consecutive samples of a track add up per pixel before the table sees them) gives
+    the reference's clouds: keys, labels and zero-charge inserts exact, charges within the usual 2 electrons --
+    forced on (`scatter_merge` 1) for workloads it would not be chosen for, both table sizes."""
+    from attpc_engine_amd.detector.simulator import simulate_batch
+    inp = Inputs(name, **kw)
+    for key, value in det_kw.items():
+        setattr(inp.config.det_params, key, value)
+    inp = _rebuild(inp)
+    seed, first = 91, 3
+    vertex, p4, status, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
+    refs = [orc.simulate(inp.det_raw, inp.layout, seed, first + e, p4[e], vertex[e], capacity=1 << 20) for e in range(n)]
+    for variant in (2, 1):
+        fresh = _abi.Context(0)
+        fresh.set_option("scatter_variant", variant)
+        fresh.set_option("scatter_merge", 1)
+        offsets, points, labels, stats = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, seed, inp.indices,
+                                                        first_event=first, ctx=fresh)
+        fresh.close()
+        assert stats["n_failed"] == 0 and stats["n_inconsistent"] == 0
+        worst = 0.0
+        for e in range(n):
+            a = sort_cloud(points[offsets[e]:offsets[e + 1]], labels[offsets[e]:offsets[e + 1]])
+            b = sort_cloud(refs[e][0], refs[e][1])
+            worst = max(worst, compare_clouds(*a, *b))
+        assert offsets[-1] > 500
+        print(name, kw, det_kw, "variant", variant, "cloud points", offsets[-1], "max |dq|", worst)
+
+
+def test_merge_variant_checksums_equal_the_default_kernel():
+    """Same events through the default kernel and the merge variant (both table sizes): identical point counts and
+    key checksums, charge checksums equal (integer sums of the same truncated terms, regrouped)."""
+    for name, n, kw in (("b10chain", 400, {}), ("o16aa", 3000, {}), ("o16aa", 600, {"path_step": 2.0e-4})):
+        got = {}
+        for variant in (2, 1):
+            for merge in (0, 1):
+                fresh = _abi.Context(0)
+                fresh.set_option("scatter_variant", variant)
+                fresh.set_option("scatter_merge", merge)
+                got[variant, merge] = _engine(Inputs(name, **kw), fresh).run(n, seed=8, first_event=21)["stats"]
+                fresh.close()
+        base = got[2, 0]
+        assert base["n_points"] > 0 and base["n_failed"] == 0
+        for key, st in got.items():
+            for k in ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_failed", "n_inconsistent"):
+                assert st[k] == base[k], (name, key, k, st[k], base[k])
+        print(name, kw, "points", base["n_points"], "retried windows default / merge (big):",
+              got[2, 0]["n_lds_overflow"], got[2, 1]["n_lds_overflow"])
 
 
 def test_fetch_with_block_reserved_rows(ctx):

@@ -558,9 +558,11 @@ struct MergeAcc {
   int pad[MESH];     // -1: no accumulator for this pixel
   uint32_t q[MESH];
   int fill;          // wave uniform: runs waiting in the wave's queue
+  uint32_t bound;    // >= every q[j]: the sum of the rows' largest pixels since the accumulators last restarted
   __device__ __forceinline__ void reset() {
     hi = MERGE_NO_HI;
     fill = 0;
+    bound = 0u;
 #pragma unroll
     for (int j = 0; j < MESH; ++j) {
       pad[j] = -1;
@@ -667,6 +669,13 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
   const float spread = (float)((6.0 / 4.9e-3) * (6.0 / 4.9e-3) * 2.0 * a.det.diffusion * a.det.dv / a.det.efield);
   const int n_slices = a.det.longitudinal_diffusion > 0.0 ? ATTPC_LONG_STEPS : 1;
   constexpr int WQ = MERGE ? MERGE_ROUND : SC_THREADS / MESH;  // entries of one full pass (select_window)
+  // aimed-at keys per window.  Merge variant: the runs reach the table in batches of a few hundred after long
+  // stretches of arithmetic, so slower probes at a fuller table cost less than the windows they save (every window
+  // ends every sequence's accumulators: up to 100 runs per sequence)
+#ifndef ATTPC_SC_MERGE_TARGET_PCT
+#define ATTPC_SC_MERGE_TARGET_PCT 50
+#endif
+  constexpr int TK = MERGE ? HASH_CAP * ATTPC_SC_MERGE_TARGET_PCT / 100 : TARGET_KEYS;
   // merge variant: this workgroup's two entry lists in global memory (list order / sorted by time bucket)
   uint2* __restrict__ const mg_list = MERGE ? a.merge_scratch + (size_t)blockIdx.x * 2u * a.merge_cap : nullptr;
   uint2* __restrict__ const mg_perm = MERGE ? mg_list + a.merge_cap : nullptr;
@@ -720,7 +729,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
         }
         for (int k = n_sim; k <= ATTPC_MAX_SIM; ++k) sh.cnt[k] = acc;
         const int zero = local_const(0);
-        sh.win_a = zero; sh.win_b = zero; sh.budget = local_const(TARGET_KEYS); sh.overflow = zero; sh.done = zero;
+        sh.win_a = zero; sh.win_b = zero; sh.budget = local_const(TK); sh.overflow = zero; sh.done = zero;
         sh.ev_failed = zero;
         sh.ev_rows = 0ull;
         sh.wg_samples += (unsigned long long)acc;
@@ -781,6 +790,10 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           }
         }
         __threadfence();  // the list is read back (by the same threads) in the sort pass below
+#ifdef ATTPC_PHASE_TIMERS
+        PHASE_SYNC;
+        PHASE_MARK(13);  // merge variant: list pass (printed as "staged")
+#endif
       } else if (sorted) {
 #pragma unroll
         for (int k = 0; k < SORT_PER_THREAD; ++k) {
@@ -888,7 +901,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
               (unsigned short)(tid + k * SC_THREADS);
         }
       }
-      if (tid < 64) select_window<WQ>(sh, 0, local_const(TARGET_KEYS), lane);
+      if (tid < 64) select_window<WQ>(sh, 0, local_const(TK), lane);
       block_sync();
       PHASE_MARK(1);
 
@@ -1113,7 +1126,9 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             }
             if (wave_total == 0) return;
             if (m.fill + wave_total > WAVE_QUEUE) {  // no room: the queued runs go to the table first
+#ifndef ATTPC_ABL_NOINSERT  // (ablation builds only)
               ok = stream_insert(sh, queue, m.fill, false, carry, claimed, diag_trips);
+#endif
               m.fill = 0;
               if (!ok) return;
             }
@@ -1135,7 +1150,9 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
                   queue[put ? e : WAVE_QUEUE] = make_uint2(m.hi | (uint32_t)m.pad[j], m.q[j]);
                   e += (int)((ends >> j) & 1u);
                 }
+#ifndef ATTPC_ABL_NOINSERT
                 ok = stream_insert(sh, queue, min(wave_total - pass0, WAVE_QUEUE), false, carry, claimed, diag_trips);
+#endif
               }
             }
           };
@@ -1167,13 +1184,22 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             const bool slow = have && ix != lut_n && (point || big);  // as in rows_round(): straight into the table
             int pad[MESH];
             {
+#ifndef ATTPC_ABL_NOGATHER
               const unsigned int col = 2u * (unsigned int)((have && !slow) ? ix : lut_n);
 #pragma unroll
               for (int j = 0; j < MESH; ++j)
                 pad[j] = (int)*reinterpret_cast<const int16_t*>(lut_bytes + (__umul24(iy[j], row_pitch) + col));
               asm volatile("" : "+v"(pad[0]), "+v"(pad[1]), "+v"(pad[2]), "+v"(pad[3]), "+v"(pad[4]), "+v"(pad[5]),
                            "+v"(pad[6]), "+v"(pad[7]), "+v"(pad[8]), "+v"(pad[9]));
+#else  // (ablation builds only, wrong results: what do the gathers cost)
+#pragma unroll
+              for (int j = 0; j < MESH; ++j) pad[j] = (have && !slow) ? (int)(((iy[j] >> 2) * 64u + ((unsigned int)ix >> 2)) & 0x1fffu) : -1;
+#endif
             }
+#ifdef ATTPC_PHASE_TIMERS
+            PHASE_SYNC;
+            PHASE_MARK(8);
+#endif
             bool slow_ok = true;
             if (__any(slow)) {
               if (slow) {
@@ -1187,23 +1213,35 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
                 }
               }
             }
-            // which accumulators end here: another time bucket / nucleus ends all ten, another pad ends one; an
-            // accumulator near 2^31 is ended as well (a pixel adds less than 2^28), so the u32 sums cannot wrap
-            const bool restart = have && word_hi != m.hi;
+            // which accumulators end here: another time bucket / nucleus ends all ten, another pad ends one; all ten
+            // are ended as well before one of them could pass 2^31 (a pixel adds less than 2^28): the u32 sums cannot wrap
+            // (the centre pixel bounds the other nine -- the weights fall off from the centre -- and is below 2^28 here)
+            const bool restart = have && (word_hi != m.hi || m.bound >= 0x70000000u);
             uint32_t ends = 0u, changed = 0u;
 #pragma unroll
             for (int j = 0; j < MESH; ++j) {
-              const bool chg = have && (restart || pad[j] != m.pad[j] || m.q[j] >= 0x80000000u);
+              const bool chg = have && (restart || pad[j] != m.pad[j]);
               changed |= chg ? (1u << j) : 0u;
               ends |= (chg && m.pad[j] >= 0) ? (1u << j) : 0u;
             }
+#ifdef ATTPC_PHASE_TIMERS
+            asm volatile("" ::"v"(ends), "v"(changed));
+            PHASE_SYNC;
+            PHASE_MARK(9);
+#endif
             emit(ends);
+#ifdef ATTPC_PHASE_TIMERS
+            PHASE_SYNC;
+            PHASE_MARK(10);
+#endif
 #pragma unroll
             for (int j = 0; j < MESH; ++j) {
               const bool chg = (changed >> j) & 1u;
               m.pad[j] = chg ? pad[j] : m.pad[j];
-              m.q[j] = (chg ? 0u : m.q[j]) + ((have && pad[j] >= 0) ? el[j] : 0u);
+              m.q[j] = (chg ? 0u : m.q[j]) + (have ? el[j] : 0u);  // (also where there is no pad: never emitted)
             }
+            // (a row that went straight to the table left no real pad behind: every accumulator restarts after it)
+            m.bound = have ? (slow ? 0u : (restart ? 0u : m.bound) + el[MESH / 2]) : m.bound;
             m.hi = have ? word_hi : m.hi;
             ok = ok && !__any(!slow_ok);
           }
@@ -1212,8 +1250,14 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
 #pragma unroll
             for (int j = 0; j < MESH; ++j) ends |= m.pad[j] >= 0 ? (1u << j) : 0u;
             emit(ends);
+#ifndef ATTPC_ABL_NOINSERT
             if (ok) ok = stream_insert(sh, queue, m.fill, true, carry, claimed, diag_trips);
+#endif
             m.fill = 0;
+#ifdef ATTPC_PHASE_TIMERS
+            PHASE_SYNC;
+            PHASE_MARK(11);
+#endif
           }
           if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);  // rows of the window's flush
           PHASE_COUNT(5, (unsigned long long)diag_trips);
@@ -1240,7 +1284,9 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           const double xlo = xy.x - 3.0 * sigma, xhi = xy.x + 3.0 * sigma;
           const double ylo = xy.y - 3.0 * sigma, yhi = xy.y + 3.0 * sigma;
           const double sx = (xhi - xlo) / (double)(MESH - 1), sy = (yhi - ylo) / (double)(MESH - 1);
-#pragma unroll
+          // (merge variant: staged inside the rows loop with the accumulators live -- rolled, so that the ten
+          //  lines' temporaries do not all need registers at once)
+#pragma unroll(MERGE ? 1 : MESH)
           for (int i = 0; i < MESH; ++i) {
             const double x = (i == MESH - 1) ? xhi : (double)i * sx + xlo;
             const double y = (i == MESH - 1) ? yhi : (double)i * sy + ylo;
@@ -1254,52 +1300,69 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           sh.st_tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
         };
         if constexpr (MERGE) {
-          // The window is mg_perm[win_r0 .. win_r0 + win_n), cut into MERGE_NSEQ sequences of L consecutive entries;
-          // round r stages entries r * MERGE_G .. of every sequence (slot = sequence * MERGE_G + k), so that a lane
-          // meets the entries of its sequence in list order, round after round, with its accumulators in registers.
+          // The window is mg_perm[win_r0 .. win_r0 + win_n), cut into MERGE_NSEQ sequences of seq_len consecutive
+          // entries.  Every WAVE works on its own MERGE_SEQ_PER_WAVE sequences without a workgroup barrier inside the
+          // window: per round a few of its lanes stage the next MERGE_G entries of each of its sequences into the wave's
+          // own staging slots, then all of its lanes step through them (rows_round_merge), accumulators in registers
+          // from round to round.  The waves drift apart, so one wave's staging loads and table inserts overlap the
+          // others' arithmetic.
           const int r0 = sh.win_r0, n_win = sh.win_n;
           const int n_rounds = (n_win + MERGE_ROUND - 1) / MERGE_ROUND;
           const int seq_len = n_rounds * MERGE_G;
+          constexpr int WAVE_SLOTS = MERGE_SEQ_PER_WAVE * MERGE_G;  // staging slots of one wave
+          static_assert(WAVE_SLOTS <= 64, "one lane per staging slot of the wave");
           MergeAcc acc;
           acc.reset();
           InsertCarry carry;
           carry.reset();
-          for (int r = 0; r < n_rounds; ++r) {
-            if (tid < MERGE_ROUND) {
-              const int sq = tid / MERGE_G;
-              const int rho = sq * seq_len + r * MERGE_G + (tid - sq * MERGE_G);
+          bool ok = true;
+          // the previous window's flush resets its table slots and reads its slot list (the queues) without a barrier
+          // behind it (it counts on the first barrier of the next staging): here the waves start on their own
+          block_sync();
+          for (int r = 0; r < n_rounds && ok; ++r) {  // wave-uniform
+            if (lane < WAVE_SLOTS) {
+              const int slot = (tid >> 6) * WAVE_SLOTS + lane;
+              const int sq = slot / MERGE_G;
+              const int rho = sq * seq_len + r * MERGE_G + (slot - sq * MERGE_G);
               if (rho < n_win) {
                 const unsigned long long raw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(mg_perm + r0 + rho),
                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const double* rec = arena + (size_t)(uint32_t)raw * 4u;
                 const uint32_t meta = (uint32_t)(raw >> 32);
-                stage_entry(tid, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1],
+                stage_entry(slot, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1],
                             (int)((meta >> 10) & 7u), (int)((meta >> 13) & 7u), 0);
               } else {
                 // no entry: the lanes of this slot skip the step -- their gathers still run, so the slot's indices
                 // must point into the table ("off the pad plane"), not at whatever the LDS held
-                sh.st_tb[tid] = -1;
-                sh.st_n[tid] = 0.0;
+                sh.st_tb[slot] = -1;
+                sh.st_n[slot] = 0.0;
 #pragma unroll
                 for (int k = 0; k < MESH; ++k) {
-                  sh.st_ix[tid][k] = (short)lut_n;
-                  sh.st_iy[tid][k] = (short)lut_n;
+                  sh.st_ix[slot][k] = (short)lut_n;
+                  sh.st_iy[slot][k] = (short)lut_n;
                 }
               }
             }
-            block_sync();
+            // (LDS operations of one wave complete in order: a fence for the compiler is all that is needed between
+            //  the lanes that stage and the lanes that read, and between this round's reads and the next round's staging)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             PHASE_MARK(3);
             PHASE_COUNT(12, 1);
-            const bool ok = rows_round_merge(acc, carry, r + 1 == n_rounds);
-            if (!ok) sh.overflow = 1;
-            if (last_of_batch && !have_next && tid == 0) {
-              next_first = take_batch();
-              have_next = true;
-            }
-            block_sync();
-            PHASE_MARK(4);
-            if (sh.overflow) break;  // uniform: every thread sees the flag after the barrier
+            ok = rows_round_merge(acc, carry, r + 1 == n_rounds);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (*reinterpret_cast<volatile int*>(&sh.overflow)) break;  // another wave gave up on this window already
           }
+          if (!ok) sh.overflow = 1;
+          if (last_of_batch && !have_next && tid == 0) {
+            next_first = take_batch();
+            have_next = true;
+          }
+          block_sync();
+          PHASE_MARK(4);
         } else if (sorted) {  // the window is perm[win_r0 .. win_r0 + win_n): stage it densely, STAGE entries per round
           const int r0 = sh.win_r0, n_win = sh.win_n;
           InsertCarry carry;
@@ -1405,7 +1468,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           clear_table(sh);
           if (tid < 64) {  // wave 0: same window start, smaller budget (a lone bucket is left to lone_bucket_kernel)
             const bool lone = win_b - win_a <= 1;  // one time bucket alone exceeds the table
-            const int budget = lone ? local_const(TARGET_KEYS) : (sh.win_samples / 2 > 0 ? sh.win_samples / 2 : 1);
+            const int budget = lone ? local_const(TK) : (sh.win_samples / 2 > 0 ? sh.win_samples / 2 : 1);
             if (tid == 0) {
               sh.retried++;
               if (lone) {
@@ -1514,11 +1577,11 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           // (the estimate counts every sample's pads anew; samples 0.1 mm apart share nearly all of theirs, so the
           // factor reaches 1/40 with the path-length step at 10x diffusion: hence the wide upper bound)
           const unsigned long long scaled =
-              n_rows ? (unsigned long long)TARGET_KEYS * (unsigned int)max(sh.win_samples, 1) / n_rows
-                     : (unsigned long long)TARGET_KEYS * BUDGET_MAX_MULT;
-          const unsigned long long top = min((unsigned long long)TARGET_KEYS * BUDGET_MAX_MULT,
-                                             (unsigned long long)max(sh.budget, TARGET_KEYS) * BUDGET_GROWTH);
-          const int budget = (int)min(max(scaled, (unsigned long long)(TARGET_KEYS / 8)), top);
+              n_rows ? (unsigned long long)TK * (unsigned int)max(sh.win_samples, 1) / n_rows
+                     : (unsigned long long)TK * BUDGET_MAX_MULT;
+          const unsigned long long top = min((unsigned long long)TK * BUDGET_MAX_MULT,
+                                             (unsigned long long)max(sh.budget, TK) * BUDGET_GROWTH);
+          const int budget = (int)min(max(scaled, (unsigned long long)(TK / 8)), top);
           select_window<WQ>(sh, win_b, budget, lane);
           PHASE_MARK(18);
         }

@@ -27,7 +27,7 @@ LONG_STEPS = 5
 EX_GAUSSIAN, EX_UNIFORM, EX_TABLE = 0, 1, 2
 POLAR_UNIFORM, POLAR_ARBITRARY = 0, 1
 
-ABI_VERSION = 2  # ATTPC_ABI_VERSION of include/attpc_engine.h this binding was written against
+ABI_VERSION = 3  # ATTPC_ABI_VERSION of include/attpc_engine.h this binding was written against
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_CAPACITY, E_NOTCONFIGURED, E_DATALOSS = 0, 1, 2, 3, 4, 5, 6
 
@@ -122,6 +122,7 @@ class RunStats(C.Structure):
         ("launches_kinematics", C.c_uint32), ("launches_tracks", C.c_uint32),
         ("launches_scatter", C.c_uint32), ("n_inconsistent", C.c_uint32),
         ("n_lone_buckets", C.c_uint64), ("n_buffer_growths", C.c_uint64),
+        ("n_tracks_capped", C.c_uint64), ("device_bytes", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:
@@ -165,7 +166,7 @@ EXPORTED_SYMBOLS = (
     "attpc_kin_run", "attpc_kin_calculate", "attpc_decay_calculate", "attpc_det_configure", "attpc_det_run",
     "attpc_sim_run", "attpc_det_tracks", "attpc_spyral_rows", "attpc_spyral_configure", "attpc_sim_run_spyral",
     "attpc_set_option", "attpc_host_alloc", "attpc_host_free", "attpc_det_scatter", "attpc_unpack_rows",
-    "attpc_unpack_spyral_rows",
+    "attpc_unpack_spyral_rows", "attpc_det_run_spyral",
 )
 
 _lib = None
@@ -218,6 +219,7 @@ def load_library() -> C.CDLL:
         C.POINTER(C.c_int32), C.POINTER(CloudOut), C.POINTER(RunStats),
     ]
     lib.attpc_sim_run_spyral.argtypes = lib.attpc_sim_run.argtypes
+    lib.attpc_det_run_spyral.argtypes = lib.attpc_det_run.argtypes
     lib.attpc_spyral_configure.argtypes = [ctxp, C.POINTER(SpyralDesc)]
     lib.attpc_det_tracks.argtypes = [
         ctxp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(EventLayout), _dp, _dp, C.c_int64,

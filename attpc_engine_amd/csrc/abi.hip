@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "tracks_args.hpp"
+#include "unpack_host.hpp"
 
 namespace {
 
@@ -121,7 +122,9 @@ struct attpc_ctx {
   double segs_per_event = 0.0;
   double blocks_per_track = 0.0;   // observed arena blocks per track
   bool prefer_big = false;         // sticky: the small scatter variant met too many lone buckets
+  bool lone_ready = false;         // lone_bucket_kernel's tables are allocated AND their zeroing has been queued
   uint64_t n_growths = 0;          // device buffers (re)allocated so far (a steady workload stops growing)
+  uint64_t device_bytes = 0;       // bytes of the grow-only device buffers (ensure()) held right now
   int64_t launch_row_cap = 0;      // row capacity given to the scatter launch queued last (<= cloud_capacity)
   uint32_t max_batch_events = 0;   // largest track batch so far: both track sets are sized for it (the set that
                                    // first meets the shorter last batch of a call would otherwise grow in the next call)
@@ -169,10 +172,12 @@ int32_t ensure(attpc_ctx* ctx, DevBuf& b, size_t bytes) {
   if (bytes <= b.bytes) return ATTPC_OK;
   ctx->n_growths++;
   if (b.p) HIP_TRY(ctx, hipFree(b.p));
+  ctx->device_bytes -= b.bytes;
   b.p = nullptr;
   b.bytes = 0;
   HIP_TRY(ctx, hipMalloc(&b.p, bytes));
   b.bytes = bytes;
+  ctx->device_bytes += bytes;
   return ATTPC_OK;
 }
 
@@ -283,19 +288,10 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const Segment* __r
 }
 
 // ---- compact transfer of delivered clouds ----
-// A cloud row in the reference's dtypes is 3 f64 + i64 = 32 bytes, but it holds 14 bits of pad, 5 of label, an
-// integer charge and one real number (the jittered time bucket): 16 bytes carry it losslessly --
-//   word 0 = the f64 time bucket + jitter as it is, word 1 = charge (45 bits) | pad << 45 (14) | label << 59 (5).
-// The delivered path is PCIe bound (234 KB per event in the reference's dtypes), so the chunk crosses the link in
-// this form into library-owned pinned staging and host threads expand it into the caller's arrays -- which then
-// need not be page-locked either.  A chunk with a row that does not fit (charge >= 2^45, label >= 32) goes the
-// plain way.
-struct PackedRow {
-  double tb;
-  unsigned long long bits;
-};
-constexpr int PACK_CHARGE_BITS = 45, PACK_PAD_BITS = 14;
-
+// The delivered path is PCIe bound (234 KB per event in the reference's dtypes), so a chunk crosses the link as 16-byte
+// records (PackedRow, unpack_host.hpp) into library-owned pinned staging and host threads expand it into the caller's
+// arrays -- which then need not be page-locked either.  A chunk with a row that does not fit (charge >= 2^45,
+// label >= 32) goes the plain way.
 __global__ __launch_bounds__(256) void pack_rows_kernel(const int64_t* __restrict__ ev_start, uint32_t n_events,
                                                         const double* __restrict__ points, const int64_t* __restrict__ labels,
                                                         PackedRow* __restrict__ packed, int64_t* __restrict__ flag) {
@@ -313,77 +309,6 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const int64_t* __restric
     packed[r] = row;
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(flag), 1ull);
-}
-
-void unpack_slice(const PackedRow* src, int64_t lo, int64_t hi, double* points, int64_t* labels) {
-  // streaming (non-temporal) stores: the expanded rows are written once and read by somebody else later, so
-  // they should not be read into this core's cache first (half the memory traffic of ordinary stores)
-  for (int64_t r = lo; r < hi; ++r) {
-    const unsigned long long b = src[r].bits;
-    __builtin_nontemporal_store((double)((b >> PACK_CHARGE_BITS) & ((1ull << PACK_PAD_BITS) - 1)), &points[3 * r]);
-    __builtin_nontemporal_store(src[r].tb, &points[3 * r + 1]);
-    __builtin_nontemporal_store((double)(b & ((1ull << PACK_CHARGE_BITS) - 1)), &points[3 * r + 2]);
-    __builtin_nontemporal_store((long long)(b >> (PACK_CHARGE_BITS + PACK_PAD_BITS)), reinterpret_cast<long long*>(&labels[r]));
-  }
-}
-
-void unpack_rows(const PackedRow* src, int64_t n, double* points, int64_t* labels, int n_threads) {
-  if (n_threads <= 0) n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-  n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n / 65536));
-  if (n_threads <= 1) {
-    unpack_slice(src, 0, n, points, labels);
-    return;
-  }
-  std::vector<std::thread> pool;
-  const int64_t per = (n + n_threads - 1) / n_threads;
-  for (int t = 1; t < n_threads; ++t)
-    pool.emplace_back(unpack_slice, src, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per), points, labels);
-  unpack_slice(src, 0, std::min<int64_t>(n, per), points, labels);
-  for (std::thread& th : pool) th.join();
-}
-
-struct SpyralHostTables {  // what convert_to_spyral (writer.py:61-112) needs beside the record
-  const double* centers;    // [n_pads, 2]
-  const double* sizes;      // [n_pads]
-  int32_t n_pads;
-  double r_max, window_edge, mm_edge, length;
-};
-
-void unpack_spyral_slice(const SpyralPacked* src, int64_t lo, int64_t hi, SpyralHostTables t, double* rows, int64_t* labels) {
-  for (int64_t r = lo; r < hi; ++r) {
-    const unsigned long long b = src[r].bits;
-    int pad = (int)((b >> SPYRAL_PACK_CHARGE_BITS) & ((1ull << SPYRAL_PACK_PAD_BITS) - 1));
-    pad = pad >= t.n_pads ? t.n_pads - 1 : pad;
-    const double q = (double)(b & ((1ull << SPYRAL_PACK_CHARGE_BITS) - 1));
-    const double tb = src[r].tb;
-    double amp = t.r_max * q;  // detector/response.py:55-57 (maximum of the clipped samples), as spyral.hip amplitude()
-    amp = amp > 4095.0 ? 4095.0 : amp;
-    double* row = rows + 8 * r;
-    __builtin_nontemporal_store(t.centers[2 * pad], &row[0]);
-    __builtin_nontemporal_store(t.centers[2 * pad + 1], &row[1]);
-    __builtin_nontemporal_store((t.window_edge - tb) / (t.window_edge - t.mm_edge) * t.length * 1000.0, &row[2]);  // writer.py:103-105
-    __builtin_nontemporal_store(amp, &row[3]);
-    __builtin_nontemporal_store(src[r].integral, &row[4]);
-    __builtin_nontemporal_store((double)pad, &row[5]);
-    __builtin_nontemporal_store(tb, &row[6]);
-    __builtin_nontemporal_store(t.sizes[pad], &row[7]);
-    __builtin_nontemporal_store((long long)(b >> (SPYRAL_PACK_CHARGE_BITS + SPYRAL_PACK_PAD_BITS)), reinterpret_cast<long long*>(&labels[r]));
-  }
-}
-
-void unpack_spyral_rows(const SpyralPacked* src, int64_t n, const SpyralHostTables& t, double* rows, int64_t* labels, int n_threads) {
-  if (n_threads <= 0) n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-  n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n / 32768));
-  if (n_threads <= 1) {
-    unpack_spyral_slice(src, 0, n, t, rows, labels);
-    return;
-  }
-  std::vector<std::thread> pool;
-  const int64_t per = (n + n_threads - 1) / n_threads;
-  for (int k = 1; k < n_threads; ++k)
-    pool.emplace_back(unpack_spyral_slice, src, std::min<int64_t>(n, k * per), std::min<int64_t>(n, (k + 1) * per), t, rows, labels);
-  unpack_spyral_slice(src, 0, std::min<int64_t>(n, per), t, rows, labels);
-  for (std::thread& th : pool) th.join();
 }
 
 __global__ __launch_bounds__(256) void count_status_kernel(const int32_t* __restrict__ status, uint32_t n,
@@ -479,7 +404,7 @@ int32_t launch_tracks(attpc_ctx* ctx, TrackSet& ts, const TrackLaunch& tl) {
 // Wait for the batch queued by launch_tracks; a batch whose arena was too small is run again with a
 // larger one.  ms / n_limit accumulate.
 int32_t finish_tracks(attpc_ctx* ctx, TrackSet& ts, const TrackLaunch& tl, TrackBuffers* out, double* ms_tracks,
-                      uint64_t* n_limit) {
+                      uint64_t* n_limit, uint64_t* n_capped = nullptr) {
   const uint32_t n_tracks = tl.n * (uint32_t)tl.lay.n_sim;
   for (int attempt = 0; attempt < 8; ++attempt) {
     HIP_TRY(ctx, hipEventSynchronize(ts.done));
@@ -491,6 +416,7 @@ int32_t finish_tracks(attpc_ctx* ctx, TrackSet& ts, const TrackLaunch& tl, Track
     if (ts.h_ctrl[2] == 0) {  // no sample was refused
       if (n_tracks) ctx->blocks_per_track = (double)ts.h_ctrl[1] / (double)n_tracks;
       if (n_limit) *n_limit += ts.h_ctrl[3];
+      if (n_capped) *n_capped += ts.h_ctrl[4];
       *out = TrackBuffers{};
       out->arena = static_cast<double*>(ts.arena.p);
       out->block_table = static_cast<int32_t*>(ts.block_table.p);
@@ -979,11 +905,14 @@ int32_t run_batch_chunks(attpc_ctx* ctx, const attpc_event_layout& lay, const Tr
   }
   if ((rc = ensure(ctx, ctx->out_ctrl, (size_t)MAX_SLOTS * CTRL_WORDS * sizeof(unsigned long long)))) return rc;
   if ((rc = ensure(ctx, ctx->lone_list, (size_t)LONE_CAPACITY * sizeof(LoneBucket)))) return rc;
-  if (!ctx->lone_chg.p) {  // lone_bucket_kernel's tables: zero once, the kernel leaves them zero
+  if (!ctx->lone_ready) {  // lone_bucket_kernel's tables: zero once, the kernel leaves them zero.  The flag is set
+                           // only when both allocations and both memsets went through (a call that failed half-way
+                           // is repeated from the start by the next run)
     if ((rc = ensure(ctx, ctx->lone_chg, (size_t)LONE_WORKGROUPS * LONE_PADS * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(ctx, ctx->lone_mask, (size_t)LONE_WORKGROUPS * (LONE_PADS / 4) * sizeof(uint32_t)))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->lone_chg.p, 0, ctx->lone_chg.bytes, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->lone_mask.p, 0, ctx->lone_mask.bytes, ctx->stream));
+    ctx->lone_ready = true;
   }
   struct Chunk { uint32_t e0, n; int slot; };
   if (!out) {
@@ -1095,7 +1024,7 @@ int32_t run_events(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t
   while (nb) {
     TrackSet& ts = ctx->tset[cur];
     TrackBuffers trk;
-    if ((rc = finish_tracks(ctx, ts, tl[cur], &trk, &st.ms_tracks, &st.n_sample_limit))) return rc;
+    if ((rc = finish_tracks(ctx, ts, tl[cur], &trk, &st.ms_tracks, &st.n_sample_limit, &st.n_tracks_capped))) return rc;
     st.launches_tracks += 1;
     if (ts.timed_kin) {
       float ms_k = 0;
@@ -1124,6 +1053,7 @@ int32_t run_events(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
   if (spyral) st.n_points = (uint64_t)row_cursor;  // rows that survive the threshold
   st.n_buffer_growths = ctx->n_growths - growths_before;
+  st.device_bytes = ctx->device_bytes;
   if (stats) *stats = st;
   if (over) return fail(ctx, ATTPC_E_CAPACITY, "cloud needs %lld rows, capacity %lld", (long long)row_cursor, (long long)out->capacity);
   if (st.n_failed || st.n_inconsistent)
@@ -1370,20 +1300,29 @@ int32_t attpc_kin_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint6
   if (!ctx->kin_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_kin_configure has not been called");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int n_rows = 4 + 2 * (ctx->kin.n_steps - 1);
+  // buffers of its own (ctx->scratch): the track sets are sized by the largest track batch met so far
+  // (max_batch_events), and a kinematics-only call of 4 chunks per launch must not set that mark for every later
+  // detector run; and nothing a failed earlier run may have left queued on any stream is overtaken
+  int32_t rc = sync_all(ctx);
+  if (rc) return rc;
   const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events) * 4;
+  const size_t cap = (size_t)std::min<uint64_t>(chunk, std::max<uint64_t>(n_events, 1));
+  if ((rc = ensure(ctx, ctx->scratch[4], cap * n_rows * 4 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch[5], cap * 3 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch[6], cap * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->scratch[7], cap * sizeof(uint32_t)))) return rc;
+  double* d_p4 = static_cast<double*>(ctx->scratch[4].p);
+  double* d_vertex = static_cast<double*>(ctx->scratch[5].p);
+  int32_t* d_status = static_cast<int32_t*>(ctx->scratch[6].p);
+  uint32_t* d_attempts = static_cast<uint32_t*>(ctx->scratch[7].p);
   for (uint64_t done = 0; done < n_events; done += chunk) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(chunk, n_events - done);
-    TrackSet& ts = ctx->tset[0];
-    int32_t rc = ensure_kin_buffers(ctx, ts, n, n_rows);
-    if (rc) return rc;
-    launch_kin_run(ctx->stream, ctx->kin, seed, first_event + done, n, static_cast<double*>(ts.p4.p),
-                   static_cast<double*>(ts.vertex.p), static_cast<int32_t*>(ts.status.p),
-                   static_cast<uint32_t*>(ts.attempts.p));
+    launch_kin_run(ctx->stream, ctx->kin, seed, first_event + done, n, d_p4, d_vertex, d_status, d_attempts);
     HIP_TRY(ctx, hipGetLastError());
-    if (p4) HIP_TRY(ctx, hipMemcpyAsync(p4 + done * n_rows * 4, ts.p4.p, (size_t)n * n_rows * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (vertex) HIP_TRY(ctx, hipMemcpyAsync(vertex + done * 3, ts.vertex.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (status) HIP_TRY(ctx, hipMemcpyAsync(status + done, ts.status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (attempts) HIP_TRY(ctx, hipMemcpyAsync(attempts + done, ts.attempts.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (p4) HIP_TRY(ctx, hipMemcpyAsync(p4 + done * n_rows * 4, d_p4, (size_t)n * n_rows * 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (vertex) HIP_TRY(ctx, hipMemcpyAsync(vertex + done * 3, d_vertex, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (status) HIP_TRY(ctx, hipMemcpyAsync(status + done, d_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (attempts) HIP_TRY(ctx, hipMemcpyAsync(attempts + done, d_attempts, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   return ATTPC_OK;
@@ -1520,6 +1459,22 @@ int32_t attpc_det_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint6
   src.h_p4 = p4;
   src.h_vertex = vertex;
   return run_events(ctx, seed, first_event, n_events, *layout, src, RunSink{}, out, false, stats);
+}
+
+int32_t attpc_det_run_spyral(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                             const attpc_event_layout* layout, const double* p4, const double* vertex,
+                             attpc_cloud_out* out, attpc_run_stats* stats) {
+  if (!ctx || !p4 || !vertex) return ATTPC_E_INVALID;
+  if (!out) return fail(ctx, ATTPC_E_INVALID, "attpc_det_run_spyral needs output buffers");
+  if (!ctx->det_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_det_configure has not been called");
+  if (!ctx->spyral_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_spyral_configure has not been called");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int32_t rc = validate_layout(ctx, layout, true);
+  if (rc) return rc;
+  RunSource src;
+  src.h_p4 = p4;
+  src.h_vertex = vertex;
+  return run_events(ctx, seed, first_event, n_events, *layout, src, RunSink{}, out, true, stats);
 }
 
 static int32_t sim_run_impl(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,

@@ -136,7 +136,8 @@ struct TrackBuffers {
   int32_t* block_table;   // [n_tracks][MAX_BLOCKS_PER_TRACK]
   int32_t* counts;        // [n_tracks] samples with >= 1 electron
   int32_t* n_steps;       // [n_tracks] ODE rows recorded (reference track length)
-  uint32_t* ctrl;         // [0] next track, [1] next arena block, [2] arena overflow flag
+  uint32_t* ctrl;         // [0] next track, [1] next arena block, [2] arena overflow flag, [3] events at the sample
+                          // limit (count_status_kernel), [4] tracks ended by the sample cap (path-length step)
   uint32_t arena_blocks;
 };
 

@@ -63,6 +63,7 @@ constexpr int SORT_SUB = 16;
 constexpr int SORT_BINS = ATTPC_NUM_TB * SORT_SUB;           // 8192
 constexpr int SORT_BINS_PER_THREAD = SORT_BINS / SP_THREADS;  // 32
 
+static_assert(SORT_BINS * sizeof(uint32_t) <= 32 * 1024, "spyral_write_kernel: the bin table is the kernel's LDS footprint");
 __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, const int64_t* __restrict__ event_start,
                                                                    const int64_t* __restrict__ kept_start,
                                                                    const double* __restrict__ points,
@@ -73,8 +74,10 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, 
                                                                    double* __restrict__ sort_key,
                                                                    SpyralPacked* __restrict__ packed,
                                                                    int64_t* __restrict__ pack_flag) {
-  __shared__ uint32_t bin_cursor[SORT_BINS];     // counts, then the next free position of every bin
-  __shared__ uint32_t bin_start[SORT_BINS + 1];
+  // counts, then the next free position of every bin; once every row is placed bin_cursor[b] is the END of bin b,
+  // i.e. the start of bin b + 1 -- so the rank pass needs no second array (32 KiB of LDS per workgroup instead of
+  // 64 KiB: four workgroups per CU instead of two, in a kernel whose cost is memory latency)
+  __shared__ uint32_t bin_cursor[SORT_BINS];
   __shared__ uint32_t wave_total[SP_THREADS / 64];
   const uint32_t e = blockIdx.x;
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -110,11 +113,9 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, 
     for (int k = 0; k < SORT_BINS_PER_THREAD; ++k) {
       const int b = t * SORT_BINS_PER_THREAD + k;
       const uint32_t c = bin_cursor[b];
-      bin_start[b] = run;
       bin_cursor[b] = run;
       run += c;
     }
-    if (t == SP_THREADS - 1) bin_start[SORT_BINS] = run;
   }
   block_sync();
   for (int64_t r = lo + t; r < hi; r += SP_THREADS) {
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(SP_THREADS) void spyral_write_kernel(SpyralDev sp, 
     const uint32_t ri = sort_idx[lo + p];
     const double tb = sort_key[lo + p];
     const int b = bin_of(tb);
-    const uint32_t b_lo = bin_start[b], b_hi = bin_start[b + 1];
+    const uint32_t b_lo = b > 0 ? bin_cursor[b - 1] : 0u, b_hi = bin_cursor[b];
     uint32_t rank = 0u;
     for (uint32_t q = b_lo; q < b_hi; ++q) {
       const double other = sort_key[lo + q];

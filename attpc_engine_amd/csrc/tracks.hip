@@ -312,7 +312,12 @@ __global__ __launch_bounds__(TRACK_THREADS, ATTPC_TRACK_MIN_WAVES) void track_ke
         count++;  // also without a block: the block counter then tells the host exactly how large the arena must be
       }
       if (active) {
-        if (!stop && k >= ATTPC_TIME_SAMPLES - 1) stop = true;  // t = 1 us: last recorded sample
+        if (!stop && k >= ATTPC_TIME_SAMPLES - 1) {  // t = 1 us: last recorded sample
+          stop = true;
+          // path-length step: the sample cap came before the end of the 1 us window -- the track is cut short
+          // (at 0.1 mm about 1 m of arc length); counted, attpc_run_stats.n_tracks_capped
+          if constexpr (PATH) atomicAdd(&a.buf.ctrl[4], 1u);
+        }
         if (stop) {
           a.buf.counts[tid] = count;
           a.buf.n_steps[tid] = k + 1;

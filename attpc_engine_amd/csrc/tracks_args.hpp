@@ -1,6 +1,7 @@
 // tracks_args.hpp -- kernel argument blocks and host launch wrappers (one per kernel file).
 #pragma once
 #include "common.hpp"
+#include "unpack_host.hpp"
 
 namespace attpc {
 
@@ -62,15 +63,7 @@ struct SpyralDev {
 void launch_spyral_count(hipStream_t s, const SpyralDev& sp, uint32_t n_events, const int64_t* event_start,
                          const double* points, uint32_t* kept);
 // rows of every event sorted by z (writer.py:236-238); sort_scratch: one u32 + one f64 per cloud row of the chunk
-// Compact transfer record of a Spyral row (24 instead of 72 bytes; the host rebuilds x, y, z, amplitude and pad
-// scale from it, include/attpc_engine.h attpc_unpack_spyral_rows): time bucket + jitter, electrons | pad << 45 |
-// label << 59, clipped integral.
-struct SpyralPacked {
-  double tb;
-  unsigned long long bits;
-  double integral;
-};
-constexpr int SPYRAL_PACK_CHARGE_BITS = 45, SPYRAL_PACK_PAD_BITS = 14;
+// (SpyralPacked: the 24-byte transfer record of a Spyral row, unpack_host.hpp)
 // packed != nullptr: write SpyralPacked records (and raise *pack_flag for a row that does not fit) instead of rows / labels
 void launch_spyral_write(hipStream_t s, const SpyralDev& sp, uint32_t n_events, const int64_t* event_start,
                          const int64_t* kept_start, const double* points, const int64_t* labels, double* rows,

@@ -31,21 +31,59 @@ def _nuclear_map():
     return nuclear_map
 
 
+def _digest(struct, arrays) -> bytes:
+    """Content of a descriptor: its scalar fields and the arrays its pointers refer to (the pointer values
+    themselves are left out -- they differ from build to build of the same content)."""
+    import ctypes
+    import hashlib
+
+    copy = type(struct).from_buffer_copy(bytes(struct))
+    for name, ctype in copy._fields_:
+        if isinstance(getattr(copy, name), ctypes._Pointer):
+            setattr(copy, name, ctypes.cast(None, ctype))
+    if hasattr(copy, "species"):
+        for sp in copy.species:
+            sp.dedx = ctypes.cast(None, type(sp.dedx))
+    h = hashlib.blake2b(bytes(copy), digest_size=16)
+    for arr in arrays:
+        h.update(np.ascontiguousarray(arr).tobytes())
+    return h.digest()
+
+
 def configure_detector(config: Config, species_keys: list[tuple[int, int]], ctx: _abi.Context,
                        ode_substeps: int = 1) -> None:
-    """Upload Config + species tables unless this ctx already holds the same ones."""
-    dp = config.det_params
-    token = (id(config), tuple(species_keys), ode_substeps, config.drift_velocity, dp.length, dp.efield,
-             dp.bfield, dp.mpgd_gain, id(dp.gas_target), dp.diffusion, dp.fano_factor, dp.w_value,
-             getattr(dp, "longitudinal_diffusion", 0.0), getattr(dp, "mc_diffusion", False),
-             getattr(dp, "path_step", 0.0))
-    if getattr(ctx, "_det_token", None) == token:
-        return
+    """Upload Config + species tables unless this ctx already holds the same ones.  "The same" is decided on the
+    CONTENT of the descriptor (every parameter, the pad look-up table, the stopping-power tables), not on object
+    identity: a parameter changed in place on the same Config object is seen."""
     nuclei = [_nuclear_map().get_data(z, a) for (z, a) in species_keys]
     desc, keep = build_det_desc(config, nuclei, ode_substeps=ode_substeps)
+    token = _digest(desc, keep)
+    if getattr(ctx, "_det_token", None) == token:
+        return
     ctx.check(ctx.lib.attpc_det_configure(ctx.handle, desc), "attpc_det_configure")
     ctx._det_token = token
     del keep
+
+
+def configure_spyral(config: Config, ctx: _abi.Context, response: np.ndarray | None = None) -> None:
+    """Upload what SpyralWriter.write needs per event (reference writer.py:164-181, 220-234) unless this ctx already
+    holds the same: the GET response of the electronics (``response``: the writer's own, writer.py:176; default
+    get_response(config)), pad centres / sizes, ADC threshold and time-bucket edges."""
+    from .response import get_response
+
+    if config.pad_centers is None:
+        raise ValueError("Pad centers are not assigned at write!")  # writer.py:220-221
+    response = np.ascontiguousarray(get_response(config) if response is None else response, dtype=np.float64)
+    centers = np.ascontiguousarray(config.pad_centers, dtype=np.float64)
+    sizes = np.ascontiguousarray(config.pad_sizes, dtype=np.float64)
+    desc = _abi.SpyralDesc(_abi.dptr(response), _abi.dptr(centers), _abi.dptr(sizes), len(sizes),
+                           int(config.elec_params.windows_edge), int(config.elec_params.micromegas_edge), 0,
+                           float(config.det_params.length), float(config.elec_params.adc_threshold))
+    token = _digest(desc, [response, centers, sizes])
+    if getattr(ctx, "_spyral_token", None) == token:
+        return
+    ctx.check(ctx.lib.attpc_spyral_configure(ctx.handle, desc), "attpc_spyral_configure")
+    ctx._spyral_token = token
 
 
 def simulate_batch(momenta: np.ndarray, vertices: np.ndarray, proton_numbers, mass_numbers,
@@ -81,6 +119,44 @@ def simulate_batch(momenta: np.ndarray, vertices: np.ndarray, proton_numbers, ma
     return offsets, points[:total], labels[:total], stats.as_dict()
 
 
+def simulate_batch_spyral(momenta: np.ndarray, vertices: np.ndarray, proton_numbers, mass_numbers,
+                          config: Config, seed: int, indices: list[int], first_event: int = 0,
+                          ctx: _abi.Context | None = None, response: np.ndarray | None = None,
+                          capacity_per_event: int = 8192):
+    """simulate() + what SpyralWriter.write does per event (convert_to_spyral, ADC threshold, z-sort; reference
+    writer.py:194-238) for n events in one launch sequence, all on the device (``attpc_det_run_spyral``) ->
+    (offsets [n+1], rows [P',8], labels [P'], event_points [n] = cloud rows of every event BEFORE the threshold,
+    stats dict)."""
+    ctx = ctx or _abi.default_context()
+    momenta = np.ascontiguousarray(momenta, dtype=np.float64)
+    vertices = np.ascontiguousarray(vertices, dtype=np.float64)
+    n = momenta.shape[0]
+    keys = species_for(proton_numbers, mass_numbers, indices)
+    configure_detector(config, keys, ctx)
+    configure_spyral(config, ctx, response)
+    layout = build_layout(proton_numbers, mass_numbers, indices, keys)
+    capacity = max(1024, int(capacity_per_event) * n)
+    while True:
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        rows = np.empty((capacity, 8), dtype=np.float64)
+        labels = np.empty(capacity, dtype=np.int64)
+        event_points = np.zeros(n, dtype=np.int64)
+        out = _abi.CloudOut(capacity, _abi.iptr(offsets, _abi.C.c_int64), _abi.dptr(rows),
+                            _abi.iptr(labels, _abi.C.c_int64), _abi.iptr(event_points, _abi.C.c_int64))
+        stats = _abi.RunStats()
+        status = ctx.lib.attpc_det_run_spyral(
+            ctx.handle, int(seed), int(first_event), n, layout, _abi.dptr(momenta),
+            _abi.dptr(vertices), out, stats,
+        )
+        if status == _abi.E_CAPACITY:
+            capacity = int(stats.n_points) + 1024
+            continue
+        ctx.check(status, "attpc_det_run_spyral")
+        break
+    total = int(offsets[n])
+    return offsets, rows[:total], labels[:total], event_points, stats.as_dict()
+
+
 def simulate(momenta: np.ndarray, vertex: np.ndarray, proton_numbers: np.ndarray,
              mass_numbers: np.ndarray, config: Config, rng: Generator, indices: list[int]):
     """One kinematics event -> (points [P,3] = pad, time bucket, electrons; labels [P])
@@ -99,7 +175,12 @@ def run_simulation(config: Config, input_path: Path, writer: SimulationWriter,
                    indices: list[int] | None = None, batch_size: int = 16384,
                    seed: int | None = None):
     """Apply the detector simulation to every event of a kinematics file (reference
-    simulator.py:118-210)."""
+    simulator.py:118-210): the writer is called once per event with a non-empty cloud, in event order, then
+    closed.  A writer that offers ``write_rows`` (SpyralWriter) receives its rows ready to store: the response
+    scaling, row conversion, ADC threshold and z-sort it would do per event in ``write`` (writer.py:194-238) run on
+    the device, fused behind the scatter, before anything crosses PCIe (``attpc_det_run_spyral``) -- the same
+    datasets as ``write`` produces, without one GPU round trip per event.  Any other SimulationWriter gets
+    ``write(points, labels, config, event)`` exactly as in the reference."""
     from ..io import KinematicsFileReader
 
     print("------- AT-TPC Simulation Engine (MI355X) -------")
@@ -112,9 +193,21 @@ def run_simulation(config: Config, input_path: Path, writer: SimulationWriter,
     print(f"Output will be written to {writer.get_directory_name()}.")
     rng = default_rng(seed)
     run_seed = int(rng.integers(0, 1 << 63))
+    fused = callable(getattr(writer, "write_rows", None))
     for start in range(0, n_events, batch_size):
         stop = min(n_events, start + batch_size)
         vertices, momenta = reader.read(start, stop)
+        if fused:
+            offsets, rows, labels, raw_points, _ = simulate_batch_spyral(
+                momenta, vertices, proton_numbers, mass_numbers, config, run_seed, nuclei_to_sim,
+                first_event=start, response=getattr(writer, "response", None),
+            )
+            for i in range(stop - start):
+                if raw_points[i] == 0:
+                    continue  # simulator.py:204-205: decided on the cloud BEFORE the threshold
+                writer.write_rows(rows[offsets[i]:offsets[i + 1]], labels[offsets[i]:offsets[i + 1]], start + i,
+                                  presorted=True)
+            continue
         offsets, points, labels, _ = simulate_batch(
             momenta, vertices, proton_numbers, mass_numbers, config, run_seed, nuclei_to_sim,
             first_event=start,

@@ -98,19 +98,9 @@ class Engine:
     def configure_spyral(self, config=None) -> None:
         """Upload what SpyralWriter needs (reference writer.py:164-181, 220-234): the GET response of
         the electronics, pad centres / sizes, ADC threshold and time-bucket edges."""
-        from .detector.response import get_response
+        from .detector.simulator import configure_spyral
 
-        config = config or self.config
-        if config.pad_centers is None:
-            raise ValueError("Pad centers are not assigned at write!")  # writer.py:220-221
-        ctx = self.ctx
-        response = np.ascontiguousarray(get_response(config), dtype=np.float64)
-        centers = np.ascontiguousarray(config.pad_centers, dtype=np.float64)
-        sizes = np.ascontiguousarray(config.pad_sizes, dtype=np.float64)
-        desc = _abi.SpyralDesc(_abi.dptr(response), _abi.dptr(centers), _abi.dptr(sizes), len(sizes),
-                               int(config.elec_params.windows_edge), int(config.elec_params.micromegas_edge), 0,
-                               float(config.det_params.length), float(config.elec_params.adc_threshold))
-        ctx.check(ctx.lib.attpc_spyral_configure(ctx.handle, desc), "attpc_spyral_configure")
+        configure_spyral(config or self.config, self.ctx)
         self._spyral_configured = True
 
     def run_spyral(self, n_events: int, seed: int = 0, first_event: int = 0, capacity_per_event: int = 6144,

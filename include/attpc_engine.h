@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ATTPC_ABI_VERSION 2
+#define ATTPC_ABI_VERSION 3
 #define ATTPC_API __attribute__((visibility("default")))
 
 /* status codes */
@@ -195,6 +195,10 @@ typedef struct attpc_run_stats {
   uint64_t n_lone_buckets;    /* time buckets that alone exceeded the LDS table and went through the
                                  direct-mapped table of lone_bucket_kernel (complete, just slower) */
   uint64_t n_buffer_growths;  /* device buffers (re)allocated during this run; 0 once the sizes have settled */
+  uint64_t n_tracks_capped;   /* path-length dE/dx step only: tracks that reached ATTPC_TIME_SAMPLES samples before the
+                                 end of the 1 us recording window and were cut there (about 1 m of arc length at a
+                                 0.1 mm step); always 0 on the reference's time grid, whose 10 001st sample IS 1 us */
+  uint64_t device_bytes;      /* device memory the context holds at the end of the run (buffers it allocated) */
 } attpc_run_stats;
 
 typedef struct attpc_ctx attpc_ctx;
@@ -344,6 +348,16 @@ ATTPC_API int32_t attpc_spyral_configure(attpc_ctx* ctx, const attpc_spyral_desc
 ATTPC_API int32_t attpc_sim_run_spyral(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
                                        const attpc_event_layout* layout, double* p4, double* vertex,
                                        int32_t* kin_status, attpc_cloud_out* out, attpc_run_stats* stats);
+
+/* attpc_det_run followed, on the device, by the same per-event work of SpyralWriter.write as in
+ * attpc_sim_run_spyral: the file-driven flow run_simulation(config, kinematics file, SpyralWriter)
+ * (detector/simulator.py:183-208 -> detector/writer.py:194-255) with kinematics read from a file (host arrays
+ * p4 [n, n_rows, 4], vertex [n, 3]) instead of generated on the device.  out->points receives rows of EIGHT doubles,
+ * every event's rows thresholded and in ascending z; out->event_points the cloud rows of every event before the
+ * threshold (simulator.py:204-205 decides "empty event" on those). */
+ATTPC_API int32_t attpc_det_run_spyral(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                                       const attpc_event_layout* layout, const double* p4, const double* vertex,
+                                       attpc_cloud_out* out, attpc_run_stats* stats);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@ ctypes Structure classes of attpc_engine_amd._abi are reused to marshal inputs.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -17,7 +18,8 @@ from attpc_engine_amd import _abi
 from attpc_engine_amd.detector.beam_pads import BEAM_PADS_ARRAY
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libattpc_oracle.so"
+# ATTPC_ORACLE_LIBRARY: another build of the same source (the sanitizer build of `make -C oracle asan`)
+LIB_PATH = Path(os.environ["ATTPC_ORACLE_LIBRARY"]) if os.environ.get("ATTPC_ORACLE_LIBRARY") else HERE / "libattpc_oracle.so"
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)

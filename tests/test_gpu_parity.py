@@ -165,7 +165,7 @@ def test_kin_sample_limit_and_samplers(ctx, orc):
 # ---------------------------------------------------------------- detector -----------------
 def _device_tracks(ctx, inp, p4, vertex, seed, first):
     from attpc_engine_amd.detector.simulator import configure_detector
-    ctx._det_token = None
+    ctx._det_token = None  # configured through the C ABI directly: the shim's cache no longer describes the device
     ctx.check(ctx.lib.attpc_det_configure(ctx.handle, inp.det), "det_configure")
     n = len(p4)
     nt = n * inp.layout.n_sim
@@ -273,10 +273,8 @@ def test_mc_diffusion_extension_vs_oracle(ctx, orc, name, d_l):
     det_raw, keep = build_det_desc(inp.config, nuclei, fold_beam=False)
     seed, first, n = 23, 4, 10
     vertex, p4, _, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
-    ctx._det_token = None
     offsets, points, labels, stats = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, seed, inp.indices,
                                                     first_event=first, ctx=ctx)
-    ctx._det_token = None
     assert stats["n_failed"] == 0 and stats["n_inconsistent"] == 0
     for e in range(n):
         ref_pts, ref_lab, _ = orc.simulate(det_raw, inp.layout, seed, first + e, p4[e], vertex[e], capacity=1 << 20)
@@ -297,10 +295,8 @@ def test_small_diffusion_many_samples_per_window(ctx, orc):
     det_raw, keep = build_det_desc(inp.config, nuclei, fold_beam=False)
     seed, first, n = 41, 3, 16
     vertex, p4, _, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
-    ctx._det_token = None
     offsets, points, labels, stats = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, seed, inp.indices,
                                                     first_event=first, ctx=ctx)
-    ctx._det_token = None
     assert stats["n_failed"] == 0
     for e in range(n):
         ref_pts, ref_lab, _ = orc.simulate(det_raw, inp.layout, seed, first + e, p4[e], vertex[e], capacity=1 << 19)
@@ -326,14 +322,12 @@ def test_zero_diffusion_and_skipped_rows(ctx, orc):
     layout = build_layout(z, inp.a, inp.indices, inp.species)
     seed, first, n = 3, 0, 12
     vertex, p4, _, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
-    ctx._det_token = None
     offsets, points, labels, stats = simulate_batch(p4, vertex, z, inp.a, inp.config, seed, inp.indices, ctx=ctx)
     assert set(np.unique(labels)) <= {2}
     for e in range(n):
         ref_pts, ref_lab, _ = orc.simulate(det_raw, layout, seed, first + e, p4[e], vertex[e])
         a = sort_cloud(points[offsets[e]:offsets[e + 1]], labels[offsets[e]:offsets[e + 1]])
         compare_clouds(*a, *sort_cloud(ref_pts, ref_lab), charge_tol=0.0)
-    ctx._det_token = None
 
 
 @pytest.mark.parametrize("name,d_l", [("o16aa", 0.3), ("be10dp", 0.05), ("be10dp", -1.0)])
@@ -351,10 +345,8 @@ def test_longitudinal_extension_vs_oracle(ctx, orc, name, d_l):
     assert det_raw.longitudinal_diffusion == abs(d_l)
     seed, first, n = 19, 2, 12
     vertex, p4, _, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
-    ctx._det_token = None
     offsets, points, labels, stats = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, seed, inp.indices,
                                                     first_event=first, ctx=ctx)
-    ctx._det_token = None
     assert stats["n_failed"] == 0
     base = Inputs(name)
     total_ref = 0
@@ -694,6 +686,92 @@ def test_run_simulation_end_to_end(tmp_path, ctx):
         abi_mod._default_ctx = old
 
 
+def test_run_simulation_with_spyral_writer_is_fused(tmp_path, ctx, monkeypatch):
+    """The reference's user flow run_simulation(config, kinematics file, SpyralWriter) (simulator.py:183-208 ->
+    writer.py:194-255): the writer's per-event work (response, row conversion, threshold, z-sort) runs on the device
+    behind the scatter (attpc_det_run_spyral) -- NO per-event attpc_spyral_rows round trip -- and the files hold the
+    same datasets as the unfused path (a writer without write_rows: one `write` call per event)."""
+    import attpc_engine_amd._abi as abi_mod
+    import attpc_engine_amd.detector.writer as writer_mod
+    from attpc_engine_amd.detector import SpyralWriter, run_simulation
+    from attpc_engine_amd.kinematics import run_kinematics_pipeline
+
+    inp = Inputs("o16aa", seed=17)
+    inp.pipeline._ctx = ctx
+    n = 70
+    kin_path = tmp_path / "kin.npz"
+    run_kinematics_pipeline(inp.pipeline, n, kin_path, batch_size=32)
+    calls = {"n": 0}
+    real_convert = writer_mod.convert_to_spyral
+
+    def counting_convert(*a, **kw):
+        calls["n"] += 1
+        return real_convert(*a, **kw)
+
+    monkeypatch.setattr(writer_mod, "convert_to_spyral", counting_convert)
+
+    class PlainWriter:  # the same writer behind the plain SimulationWriter protocol (no write_rows)
+        def __init__(self, inner):
+            self.inner = inner
+
+        def write(self, data, labels, config, event_number):
+            self.inner.write(data, labels, config, event_number)
+
+        def get_directory_name(self):
+            return self.inner.get_directory_name()
+
+        def close(self):
+            self.inner.close()
+
+    old = abi_mod._default_ctx
+    abi_mod._default_ctx = ctx
+    try:
+        fused_dir, plain_dir = tmp_path / "fused", tmp_path / "plain"
+        fused_dir.mkdir()
+        plain_dir.mkdir()
+        run_simulation(inp.config, kin_path, SpyralWriter(fused_dir, inp.config, max_events_per_file=25), batch_size=30, seed=9)
+        assert calls["n"] == 0          # nothing went through attpc_spyral_rows
+        run_simulation(inp.config, kin_path, PlainWriter(SpyralWriter(plain_dir, inp.config, max_events_per_file=25)),
+                       batch_size=30, seed=9)
+        assert calls["n"] > n // 2      # the unfused path: one device round trip per written event
+    finally:
+        abi_mod._default_ctx = old
+    fused_files, plain_files = sorted(fused_dir.iterdir()), sorted(plain_dir.iterdir())
+    assert [f.name for f in fused_files] == [f.name for f in plain_files] and len(fused_files) >= 2
+    n_sets = 0
+    for ff, pf in zip(fused_files, plain_files):
+        a, b = np.load(ff), np.load(pf)
+        assert sorted(a.files) == sorted(b.files)      # same datasets, same attributes, same roll-over
+        for key in a.files:
+            if key.startswith("cloud/cloud_") and "@" not in key:
+                ra, rb = a[key], b[key]
+                la, lb = a[key.replace("cloud_", "labels_")], b[key.replace("cloud_", "labels_")]
+                assert ra.shape == rb.shape and (np.diff(ra[:, 2]) >= 0).all()
+                oa, ob = np.lexsort((ra[:, 5], ra[:, 2])), np.lexsort((rb[:, 5], rb[:, 2]))  # ties in z: by pad
+                np.testing.assert_allclose(ra[oa], rb[ob], rtol=1e-12, atol=0)
+                np.testing.assert_array_equal(la[oa], lb[ob])
+                n_sets += 1
+            elif "@" in key:
+                np.testing.assert_array_equal(a[key], b[key])
+    assert n_sets > n // 2
+
+
+def test_configure_sees_parameters_changed_in_place(ctx, orc):
+    """The shim's "already configured" test is on the descriptor's content: an ElectronicsParams field changed in
+    place on the same Config object changes the next run (it used to be keyed on object identity)."""
+    from attpc_engine_amd.detector.simulator import simulate_batch
+    inp = Inputs("be10dp")
+    vertex, p4, _, _ = orc.kin_batch(inp.kin, 5, 0, 6, threads=4)
+    a = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, 5, inp.indices, ctx=ctx)
+    inp.config.elec_params.micromegas_edge = 60  # moves every sample 50 time buckets later
+    b = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, 5, inp.indices, ctx=ctx)
+    assert a[1].shape != b[1].shape or not np.array_equal(a[1], b[1])
+    inp2 = _rebuild(inp)
+    for e in range(6):
+        ref_pts, ref_lab, _ = orc.simulate(inp2.det_raw, inp2.layout, 5, e, p4[e], vertex[e], capacity=1 << 19)
+        compare_clouds(*sort_cloud(b[1][b[0][e]:b[0][e + 1]], b[2][b[0][e]:b[0][e + 1]]), *sort_cloud(ref_pts, ref_lab))
+
+
 def test_reaction_errors_and_config_paths(tmp_path, ctx):
     """ValueError conventions of the reference (reaction.py:136-143) and custom PadParams paths."""
     from attpc_engine_amd import GasTarget
@@ -727,13 +805,11 @@ def test_reaction_errors_and_config_paths(tmp_path, ctx):
     inp = Inputs("be10dp")
     vertex, p4 = inp.pipeline.run_many(6, first_event=3, seed=1)
     a = simulate_batch(p4, vertex, inp.z, inp.a, base, 9, inp.indices, ctx=ctx)
-    ctx._det_token = None
     b = simulate_batch(p4, vertex, inp.z, inp.a, custom, 9, inp.indices, ctx=ctx)
     np.testing.assert_array_equal(a[0], b[0])
     for e in range(6):
         lo, hi = a[0][e], a[0][e + 1]
         compare_clouds(*sort_cloud(a[1][lo:hi], a[2][lo:hi]), *sort_cloud(b[1][lo:hi], b[2][lo:hi]), charge_tol=0.0)
-    ctx._det_token = None
 
 
 def test_fused_spyral_rows(tmp_path, ctx, orc):
@@ -849,7 +925,6 @@ def test_spyral_delivery_plain_and_compact_agree(ctx):
         assert a["offsets"][-1] > 1000
         if gain > 175000:
             assert a["rows"][:, 3].max() == 4095.0  # saturated amplitudes: these charges are far beyond 2^45
-    ctx._det_token = None
 
 
 def test_spyral_rows_golden(golden_dir, ctx):

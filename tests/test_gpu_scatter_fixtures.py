@@ -33,7 +33,7 @@ def _configure(ctx, diffusion, fold=True, **det_kw):
     for k, v in det_kw.items():
         setattr(cfg.det_params, k, v)
     desc, keep = build_det_desc(cfg, [nuclear_map.get_data(1, 1)], fold_beam=True)
-    ctx._det_token = None
+    ctx._det_token = None  # configured through the C ABI directly: the shim's cache no longer describes the device
     ctx.check(ctx.lib.attpc_det_configure(ctx.handle, desc), "attpc_det_configure")
     raw, keep_raw = build_det_desc(cfg, [nuclear_map.get_data(1, 1)], fold_beam=False)
     return cfg, raw, (keep, keep_raw)
@@ -136,7 +136,7 @@ def test_track_kernel_vs_reference_radau(golden_dir, ctx):
 
     g = np.load(golden_dir / "tracks.npz")
     det, keep = _golden_det(g, fano=0.0)
-    ctx._det_token = None
+    ctx._det_token = None  # configured through the C ABI directly: the shim's cache no longer describes the device
     ctx.check(ctx.lib.attpc_det_configure(ctx.handle, det), "attpc_det_configure")
     species = [tuple(s) for s in g["species"]]
     n = len(g["cases"])
@@ -290,8 +290,8 @@ def test_pad_ids_outside_the_key_range_are_rejected(ctx):
     lut = np.ctypeslib.as_array(desc.pad_lut, shape=(desc.lut_n * desc.lut_n,)).copy()
     lut[5] = 16384
     desc.pad_lut = lut.ctypes.data_as(C.POINTER(C.c_int16))
-    ctx._det_token = None
     with pytest.raises(ValueError, match="pad id"):
+        ctx._det_token = None  # configured through the C ABI directly: the shim's cache no longer describes the device
         ctx.check(ctx.lib.attpc_det_configure(ctx.handle, desc), "attpc_det_configure")
 
 

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_header_symbols():
     assert declared == set(_abi.EXPORTED_SYMBOLS), declared ^ set(_abi.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.attpc_version() == _abi.ABI_VERSION == 2
+    assert lib.attpc_version() == _abi.ABI_VERSION == 3
 
 
 def test_abi_struct_layout_matches_header():

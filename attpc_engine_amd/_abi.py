@@ -166,7 +166,7 @@ EXPORTED_SYMBOLS = (
     "attpc_kin_run", "attpc_kin_calculate", "attpc_decay_calculate", "attpc_det_configure", "attpc_det_run",
     "attpc_sim_run", "attpc_det_tracks", "attpc_spyral_rows", "attpc_spyral_configure", "attpc_sim_run_spyral",
     "attpc_set_option", "attpc_host_alloc", "attpc_host_free", "attpc_det_scatter", "attpc_unpack_rows",
-    "attpc_unpack_spyral_rows", "attpc_det_run_spyral",
+    "attpc_unpack_spyral_rows", "attpc_det_run_spyral", "attpc_sim_hint_next", "attpc_unpack_rows8",
 )
 
 _lib = None
@@ -220,6 +220,7 @@ def load_library() -> C.CDLL:
     ]
     lib.attpc_sim_run_spyral.argtypes = lib.attpc_sim_run.argtypes
     lib.attpc_det_run_spyral.argtypes = lib.attpc_det_run.argtypes
+    lib.attpc_sim_hint_next.argtypes = [ctxp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(EventLayout)]
     lib.attpc_spyral_configure.argtypes = [ctxp, C.POINTER(SpyralDesc)]
     lib.attpc_det_tracks.argtypes = [
         ctxp, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(EventLayout), _dp, _dp, C.c_int64,
@@ -233,6 +234,8 @@ def load_library() -> C.CDLL:
     lib.attpc_host_alloc.argtypes = [ctxp, C.c_uint64, C.POINTER(C.c_void_p)]
     lib.attpc_host_free.argtypes = [ctxp, C.c_void_p]
     lib.attpc_unpack_rows.argtypes = [C.c_void_p, C.c_int64, _dp, C.POINTER(C.c_int64), C.c_int32]
+    lib.attpc_unpack_rows8.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_uint64, C.c_uint64, _dp,
+                                       C.POINTER(C.c_int64), C.c_int32]
     lib.attpc_unpack_spyral_rows.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, C.c_int32, C.c_double, C.c_int32, C.c_int32,
                                              C.c_double, _dp, C.POINTER(C.c_int64), C.c_int32]
     lib.attpc_spyral_rows.argtypes = [

@@ -82,6 +82,11 @@ struct UnpackJob {  // one chunk's records in pinned staging -> the caller's arr
   double* points = nullptr;   // [rows, 3] cloud rows, or [rows, 8] Spyral rows when `spyral`
   int64_t* labels = nullptr;
   bool spyral = false;
+  // 8-byte cloud records: what the host needs to regenerate the jitter (the job's own copy of the chunk's CSR
+  // offsets: the set's pinned copy is overwritten by the chunk after next while this job may still run)
+  bool tight = false;
+  uint64_t seed = 0, first_event = 0;
+  std::vector<int64_t> offsets;
 };
 
 }  // namespace
@@ -96,7 +101,8 @@ struct attpc_ctx {
   int32_t chunk_events = 65536;
   int opt_variant = 0;             // 0 auto, 1 small, 2 big
   bool opt_tiny = false;
-  bool opt_compact = true;         // clouds cross PCIe as 16-byte records and are expanded by host threads
+  int opt_compact = 2;             // delivered clouds cross PCIe as 8-byte (2) / 16-byte (1) records and are expanded
+                                   // by host threads, or in the reference's dtypes (0)
   int opt_unpack_threads = 0;      // 0: min(16, hardware threads)
   int opt_deliver_chunk = 8192;    // events per chunk when clouds are delivered (the pipeline's fill and drain time)
   int opt_merge = -1;              // scatter kernel's merge variant: -1 automatic (path-length dE/dx step), 0 never, 1 always
@@ -128,6 +134,17 @@ struct attpc_ctx {
   int64_t launch_row_cap = 0;      // row capacity given to the scatter launch queued last (<= cloud_capacity)
   uint32_t max_batch_events = 0;   // largest track batch so far: both track sets are sized for it (the set that
                                    // first meets the shorter last batch of a call would otherwise grow in the next call)
+
+  // attpc_sim_hint_next: the call after the one that comes next.  `hint_*` is what the caller announced; once the
+  // run it was given to has queued that call's first track batch (behind its own last scatter launches) `pre_valid`
+  // says which track set holds it.
+  bool hint_valid = false, pre_valid = false;
+  uint64_t hint_seed = 0, hint_first = 0, hint_n = 0;
+  attpc_event_layout hint_lay{};
+  int pre_set = 0;
+  uint64_t pre_seed = 0, pre_first = 0;
+  uint32_t pre_nb = 0;
+  attpc_event_layout pre_lay{};
 
   bool spyral_ready = false;
   SpyralDev spyral{};
@@ -201,6 +218,25 @@ int32_t sync_all(attpc_ctx* ctx) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
   return ATTPC_OK;
+}
+
+// A first track batch queued ahead for a call that does not come (another entry point, other events, a new
+// configuration): let it finish and forget it.
+int32_t drop_prefetch(attpc_ctx* ctx) {
+  ctx->hint_valid = false;
+  if (!ctx->pre_valid) return ATTPC_OK;
+  ctx->pre_valid = false;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_t));
+  return ATTPC_OK;
+}
+
+bool same_layout(const attpc_event_layout& a, const attpc_event_layout& b) {
+  if (a.n_rows != b.n_rows || a.n_sim != b.n_sim) return false;
+  for (int i = 0; i < a.n_sim; ++i)
+    if (a.indices[i] != b.indices[i]) return false;
+  for (int i = 0; i < a.n_rows; ++i)
+    if (a.species_of_row[i] != b.species_of_row[i]) return false;
+  return true;
 }
 
 int32_t validate_layout(attpc_ctx* ctx, const attpc_event_layout* lay, bool with_species) {
@@ -292,23 +328,37 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const Segment* __r
 // records (PackedRow, unpack_host.hpp) into library-owned pinned staging and host threads expand it into the caller's
 // arrays -- which then need not be page-locked either.  A chunk with a row that does not fit (charge >= 2^45,
 // label >= 32) goes the plain way.
+// tight != 0: the 8-byte record (PackedRow8, unpack_host.hpp) -- the jitter is not sent at all: it is a pure function of
+// (seed, event, time bucket, pad), and the host regenerates it with the same Philox2x32-7.  flag[0] != 0: a row does not fit
+// the 16-byte record; flag[1] != 0: a row does not fit the 8-byte one (charge >= 2^36, or a jittered time bucket that
+// is a whole number -- tb + U rounded up to tb + 1, about one row in 1e13 -- from which the bucket cannot be read back).
 __global__ __launch_bounds__(256) void pack_rows_kernel(const int64_t* __restrict__ ev_start, uint32_t n_events,
                                                         const double* __restrict__ points, const int64_t* __restrict__ labels,
-                                                        PackedRow* __restrict__ packed, int64_t* __restrict__ flag) {
+                                                        PackedRow* __restrict__ packed, int64_t* __restrict__ flag, int tight) {
   const int64_t total = ev_start[n_events];
-  bool bad = false;
+  bool bad = false, bad8 = false;
+  unsigned long long* __restrict__ packed8 = reinterpret_cast<unsigned long long*>(packed);
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < total; r += (int64_t)gridDim.x * 256) {
-    const double padf = points[3 * r], q = points[3 * r + 2];
+    const double padf = points[3 * r], tbj = points[3 * r + 1], q = points[3 * r + 2];
     const long long label = labels[r];
     const unsigned long long charge = (unsigned long long)q, pad = (unsigned long long)padf;
     bad = bad || !(q >= 0.0) || charge >= (1ull << PACK_CHARGE_BITS) || pad >= (1ull << PACK_PAD_BITS) || label < 0 || label >= 32;
-    PackedRow row;
-    row.tb = points[3 * r + 1];
-    row.bits = (charge & ((1ull << PACK_CHARGE_BITS) - 1)) | (pad << PACK_CHARGE_BITS) |
-               ((unsigned long long)label << (PACK_CHARGE_BITS + PACK_PAD_BITS));
-    packed[r] = row;
+    if (tight) {
+      const double tbf = floor(tbj);
+      bad8 = bad8 || charge >= (1ull << PACK8_CHARGE_BITS) || !(tbf >= 0.0) || tbf >= (double)(1 << PACK8_TB_BITS) || tbf == tbj;
+      packed8[r] = (charge & ((1ull << PACK8_CHARGE_BITS) - 1)) | ((unsigned long long)tbf << PACK8_CHARGE_BITS) |
+                   (pad << (PACK8_CHARGE_BITS + PACK8_TB_BITS)) |
+                   ((unsigned long long)label << (PACK8_CHARGE_BITS + PACK8_TB_BITS + PACK_PAD_BITS));
+    } else {
+      PackedRow row;
+      row.tb = tbj;
+      row.bits = (charge & ((1ull << PACK_CHARGE_BITS) - 1)) | (pad << PACK_CHARGE_BITS) |
+                 ((unsigned long long)label << (PACK_CHARGE_BITS + PACK_PAD_BITS));
+      packed[r] = row;
+    }
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(flag), 1ull);
+  if (__any(bad8 || bad) && (threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(flag) + 1, 1ull);
 }
 
 __global__ __launch_bounds__(256) void count_status_kernel(const int32_t* __restrict__ status, uint32_t n,
@@ -675,7 +725,8 @@ int32_t enqueue_assembly(attpc_ctx* ctx, int slot, AsmSet& as, uint32_t n, bool 
       HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 2 * sizeof(int64_t), ctx->stream));
       hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)ctx->n_cus * 8u), dim3(256), 0, ctx->stream,
                          static_cast<const int64_t*>(as.ev_start.p), n, static_cast<const double*>(as.points.p),
-                         static_cast<const int64_t*>(as.labels.p), static_cast<PackedRow*>(as.packed.p), d_flag);
+                         static_cast<const int64_t*>(as.labels.p), static_cast<PackedRow*>(as.packed.p), d_flag,
+                         ctx->opt_compact == 2 ? 1 : 0);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipMemcpyAsync(as.h_total, d_flag, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -736,6 +787,9 @@ void unpacker_main(attpc_ctx* ctx) {
       t.mm_edge = ctx->spyral.mm_edge;
       t.length = ctx->spyral.length;
       unpack_spyral_rows(static_cast<const SpyralPacked*>(job.src), job.rows, t, job.points, job.labels, ctx->opt_unpack_threads);
+    } else if (ok && job.tight) {
+      unpack_rows8(static_cast<const unsigned long long*>(job.src), job.rows, job.offsets.data(), (int64_t)job.offsets.size() - 1,
+                   job.seed, job.first_event, job.points, job.labels, ctx->opt_unpack_threads);
     } else if (ok) {
       unpack_rows(static_cast<const PackedRow*>(job.src), job.rows, job.points, job.labels, ctx->opt_unpack_threads);
     }
@@ -775,7 +829,7 @@ struct UnpackDrain {
 
 // The chunk in `as` is ready on the device: write its offsets, queue its copy to the caller's arrays on C.
 int32_t deliver_chunk(attpc_ctx* ctx, AsmSet& as, uint32_t n, uint64_t chunk_first_local, bool spyral, attpc_cloud_out* out,
-                      int64_t* row_cursor, bool* over_capacity) {
+                      int64_t* row_cursor, bool* over_capacity, uint64_t seed, uint64_t chunk_first_global) {
   const int64_t base = *row_cursor;
   const int64_t total = as.h_start[n];
   if (out->offsets)
@@ -789,6 +843,16 @@ int32_t deliver_chunk(attpc_ctx* ctx, AsmSet& as, uint32_t n, uint64_t chunk_fir
     return ATTPC_OK;
   }
   const bool compact = ctx->opt_compact && as.h_total[0] == 0;  // [0]: a row of the chunk does not fit the record
+  const bool tight = compact && !spyral && ctx->opt_compact == 2 && as.h_total[1] == 0;  // [1]: ... the 8-byte record
+  if (total > 0 && compact && !spyral && ctx->opt_compact == 2 && !tight) {
+    // the pack kernel wrote 8-byte records and one of them does not hold its row: pack again, 16 bytes per row (rare)
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)ctx->n_cus * 8u), dim3(256), 0, ctx->stream,
+                       static_cast<const int64_t*>(as.ev_start.p), n, static_cast<const double*>(as.points.p),
+                       static_cast<const int64_t*>(as.labels.p), static_cast<PackedRow*>(as.packed.p),
+                       reinterpret_cast<int64_t*>(static_cast<char*>(as.packed.p) + as.row_cap * sizeof(PackedRow)), 0);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   if (total > 0 && spyral && ctx->opt_compact && !compact) {
     // the write kernel produced records only: produce the rows themselves for the plain copy below (rare)
     launch_spyral_write(ctx->stream, ctx->spyral, n, static_cast<const int64_t*>(as.ev_start.p),
@@ -800,7 +864,7 @@ int32_t deliver_chunk(attpc_ctx* ctx, AsmSet& as, uint32_t n, uint64_t chunk_fir
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   if (total > 0 && compact) {
-    const size_t bytes = (size_t)total * (spyral ? sizeof(SpyralPacked) : sizeof(PackedRow));
+    const size_t bytes = (size_t)total * (spyral ? sizeof(SpyralPacked) : (tight ? sizeof(unsigned long long) : sizeof(PackedRow)));
     {  // the staging's previous occupant (two chunks back) must have been expanded
       int32_t rcw = wait_unpacked(ctx, as.unpack_ticket);
       if (rcw) return rcw;
@@ -821,6 +885,12 @@ int32_t deliver_chunk(attpc_ctx* ctx, AsmSet& as, uint32_t n, uint64_t chunk_fir
     job.points = out->points + base * (spyral ? 8 : 3);
     job.labels = out->labels + base;
     job.spyral = spyral;
+    if (tight) {
+      job.tight = true;
+      job.seed = seed;
+      job.first_event = chunk_first_global;
+      job.offsets.assign(as.h_start, as.h_start + n + 1);
+    }
     as.unpack_ticket = submit_unpack(ctx, job);
     return ATTPC_OK;
   } else if (total > 0) {
@@ -965,7 +1035,7 @@ int32_t run_batch_chunks(attpc_ctx* ctx, const attpc_event_layout& lay, const Tr
     }
     if (r.overflow) return fail(ctx, ATTPC_E_HIP, "point cloud did not fit after repeated buffer growth");
     accumulate(st, r);
-    return deliver_chunk(ctx, as, c.n, batch_first_local + c.e0, spyral, out, row_cursor, over);
+    return deliver_chunk(ctx, as, c.n, batch_first_local + c.e0, spyral, out, row_cursor, over, seed, batch_first_global + c.e0);
   };
   while (e0 < nb) {
     const bool pilot = ctx->rows_per_event <= 0.0;  // only ever true with nothing in flight
@@ -1019,8 +1089,27 @@ int32_t run_events(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t
     if (ctx->blocks_per_track <= 0.0) want = std::min<uint64_t>(want, std::min<uint64_t>(chunk, 16384));  // pilot: sizes the arena
     return (uint32_t)std::min<uint64_t>(want, n_events - at);
   };
+  // the caller's announcement of the call AFTER this one (attpc_sim_hint_next) belongs to this run alone
+  const bool hinted = ctx->hint_valid && src.from_kernel;
+  const uint64_t hint_seed = ctx->hint_seed, hint_first = ctx->hint_first, hint_n = ctx->hint_n;
+  const attpc_event_layout hint_lay = ctx->hint_lay;
+  ctx->hint_valid = false;
   uint32_t nb = n_events ? batch_size(0) : 0;
-  if (nb && (rc = queue_batch(ctx, ctx->tset[cur], tl[cur], lay, src, seed, first_event, 0, nb, n_rows))) return rc;
+  if (ctx->pre_valid && src.from_kernel && nb && ctx->pre_seed == seed && ctx->pre_first == first_event &&
+      ctx->pre_nb <= n_events && same_layout(ctx->pre_lay, lay)) {
+    // the previous run queued this call's first track batch behind its own last scatter launches: take it over
+    ctx->pre_valid = false;
+    cur = ctx->pre_set;
+    nb = ctx->pre_nb;
+    tl[cur].lay = lay;
+    tl[cur].seed = seed;
+    tl[cur].first_event = first_event;
+    tl[cur].n = nb;
+    tl[cur].use_status = true;
+  } else {
+    if ((rc = drop_prefetch(ctx))) return rc;
+    if (nb && (rc = queue_batch(ctx, ctx->tset[cur], tl[cur], lay, src, seed, first_event, 0, nb, n_rows))) return rc;
+  }
   while (nb) {
     TrackSet& ts = ctx->tset[cur];
     TrackBuffers trk;
@@ -1037,7 +1126,24 @@ int32_t run_events(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t
     const uint64_t next_b0 = b0 + nb;
     uint32_t next_nb = 0;
     auto queue_next = [&]() -> int32_t {
-      if (next_b0 >= n_events) return ATTPC_OK;
+      if (next_b0 >= n_events) {
+        // the last batch of this call: the other track set is free, and the caller said what comes next -- that call's
+        // first kinematics + track batch goes onto the low-priority stream now, behind this call's last scatter
+        // launches, instead of standing alone at the head of the next call
+        if (!hinted || hint_n == 0) return ATTPC_OK;
+        const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events);
+        const uint32_t pre_nb = (uint32_t)std::min<uint64_t>(track_batch_events(ctx, hint_lay, chunk), hint_n);
+        TrackLaunch pre_tl;
+        int32_t rcq = queue_batch(ctx, ctx->tset[cur ^ 1], pre_tl, hint_lay, src, hint_seed, hint_first, 0, pre_nb, hint_lay.n_rows);
+        if (rcq) return rcq;
+        ctx->pre_valid = true;
+        ctx->pre_set = cur ^ 1;
+        ctx->pre_seed = hint_seed;
+        ctx->pre_first = hint_first;
+        ctx->pre_nb = pre_nb;
+        ctx->pre_lay = hint_lay;
+        return ATTPC_OK;
+      }
       next_nb = batch_size(next_b0);
       return queue_batch(ctx, ctx->tset[cur ^ 1], tl[cur ^ 1], lay, src, seed, first_event, next_b0, next_nb, n_rows);
     };
@@ -1180,7 +1286,8 @@ int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value) {
   } else if (key == "tiny_buffers") {
     ctx->opt_tiny = value != 0;
   } else if (key == "compact_transfer") {
-    ctx->opt_compact = value != 0;
+    if (value < 0 || value > 2) return fail(ctx, ATTPC_E_INVALID, "compact_transfer must be 0, 1 or 2");
+    ctx->opt_compact = (int)value;
   } else if (key == "deliver_chunk_events") {
     if (value < 64 || value > (1 << 20)) return fail(ctx, ATTPC_E_INVALID, "deliver_chunk_events must be 64..1048576");
     ctx->opt_deliver_chunk = (int)value;
@@ -1227,6 +1334,14 @@ int32_t attpc_unpack_rows(const void* packed, int64_t n_rows, double* points, in
   return ATTPC_OK;
 }
 
+int32_t attpc_unpack_rows8(const void* packed, int64_t n_rows, const int64_t* offsets, int64_t n_events, uint64_t seed,
+                           uint64_t first_event, double* points, int64_t* labels, int32_t n_threads) {
+  if (n_rows < 0 || n_events < 0 || !offsets || (n_rows > 0 && (!packed || !points || !labels))) return ATTPC_E_INVALID;
+  if (offsets[n_events] != offsets[0] + n_rows) return ATTPC_E_INVALID;
+  unpack_rows8(static_cast<const unsigned long long*>(packed), n_rows, offsets, n_events, seed, first_event, points, labels, n_threads);
+  return ATTPC_OK;
+}
+
 int32_t attpc_unpack_spyral_rows(const void* packed, int64_t n_rows, const double* pad_centers, const double* pad_sizes,
                                  int32_t n_pads, double r_max, int32_t windows_edge, int32_t micromegas_edge, double length,
                                  double* rows, int64_t* labels, int32_t n_threads) {
@@ -1254,6 +1369,7 @@ int32_t attpc_kin_configure(attpc_ctx* ctx, const attpc_kin_desc* d) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (d->n_steps < 1 || d->n_steps > ATTPC_MAX_STEPS) return fail(ctx, ATTPC_E_INVALID, "n_steps=%d", d->n_steps);
   if (d->sample_limit < 1) return fail(ctx, ATTPC_E_INVALID, "sample_limit=%d", d->sample_limit);
+  { int32_t rc0 = drop_prefetch(ctx); if (rc0) return rc0; }
   { int32_t rc0 = sync_all(ctx); if (rc0) return rc0; }
   free_all(ctx->kin_allocs);
   ctx->kin_ready = false;
@@ -1400,6 +1516,7 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
       if (d->pad_lut[i] < -1 || d->pad_lut[i] >= LONE_PADS)
         return fail(ctx, ATTPC_E_INVALID, "pad look-up table holds pad id %d at cell %zu: ids must be in [-1, %d]", (int)d->pad_lut[i], i, LONE_PADS - 1);
   }
+  { int32_t rc0 = drop_prefetch(ctx); if (rc0) return rc0; }
   { int32_t rc0 = sync_all(ctx); if (rc0) return rc0; }
   free_all(ctx->det_allocs);
   ctx->det_ready = false;
@@ -1511,6 +1628,23 @@ int32_t attpc_sim_run_spyral(attpc_ctx* ctx, uint64_t seed, uint64_t first_event
   return sim_run_impl(ctx, seed, first_event, n_events, layout, p4, vertex, kin_status, out, stats, true);
 }
 
+int32_t attpc_sim_hint_next(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                            const attpc_event_layout* layout) {
+  if (!ctx) return ATTPC_E_INVALID;
+  ctx->hint_valid = false;
+  if (!layout || n_events == 0) return ATTPC_OK;  // "nothing known about the next call"
+  if (!ctx->kin_ready || !ctx->det_ready) return fail(ctx, ATTPC_E_NOTCONFIGURED, "attpc_sim_hint_next before the configure calls");
+  int32_t rc = validate_layout(ctx, layout, true);
+  if (rc) return rc;
+  if (layout->n_rows != 4 + 2 * (ctx->kin.n_steps - 1)) return fail(ctx, ATTPC_E_INVALID, "layout.n_rows does not match the pipeline");
+  ctx->hint_valid = true;
+  ctx->hint_seed = seed;
+  ctx->hint_first = first_event;
+  ctx->hint_n = n_events;
+  ctx->hint_lay = *layout;
+  return ATTPC_OK;
+}
+
 int32_t attpc_spyral_configure(attpc_ctx* ctx, const attpc_spyral_desc* d) {
   if (!ctx || !d || !d->response || !d->pad_centers || !d->pad_sizes || d->n_pads < 1) return ATTPC_E_INVALID;
   if (d->windows_edge <= d->micromegas_edge) return fail(ctx, ATTPC_E_INVALID, "windows_edge <= micromegas_edge");
@@ -1552,6 +1686,7 @@ int32_t attpc_det_tracks(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, ui
   int32_t rc = validate_layout(ctx, layout, true);
   if (rc) return rc;
   if (n_events > (uint64_t)ctx->chunk_events) return fail(ctx, ATTPC_E_INVALID, "attpc_det_tracks handles at most one chunk");
+  if ((rc = drop_prefetch(ctx))) return rc;
   const uint32_t n = (uint32_t)n_events;
   TrackSet& ts = ctx->tset[0];
   TrackLaunch tl;
@@ -1593,6 +1728,7 @@ int32_t attpc_det_scatter(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, u
   int32_t rc = validate_layout(ctx, layout, false);
   if (rc) return rc;
   if (n_events > (uint64_t)ctx->chunk_events) return fail(ctx, ATTPC_E_INVALID, "attpc_det_scatter handles at most one chunk");
+  if ((rc = drop_prefetch(ctx))) return rc;
   const uint32_t n = (uint32_t)n_events;
   const uint32_t n_tracks = n * (uint32_t)layout->n_sim;
   // pack the samples into arena blocks, one chain of consecutive blocks per track

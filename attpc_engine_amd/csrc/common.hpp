@@ -20,7 +20,7 @@ constexpr double TWO_PI = 2.0 * PI;
 // RNG domains of the counter word (see DESIGN.md "Random streams")
 constexpr uint32_t DOMAIN_KIN = 0u;       // index = attempt * 64 + slot
 constexpr uint32_t DOMAIN_FANO0 = 1u;     // + row of the nucleus; index = sample >> 1
-constexpr uint32_t DOMAIN_JITTER = 0x100u; // index = tb << 14 | pad; Philox4x32-7
+constexpr uint32_t DOMAIN_JITTER = 0x100u; // folded into the key word of jitter_uniform() (Philox2x32-7)
 constexpr uint32_t DOMAIN_MC = 0x200u;     // + entry number of the event; index = primary electron
 constexpr uint32_t KIN_SLOTS = 64u;
 
@@ -57,9 +57,8 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
-// two uniforms in [0,1) for (seed, event, index, domain).  ROUNDS = 10 everywhere except the
-// time-bucket jitter (one draw per cloud point), which uses the 7-round variant: the fewest rounds that
-// pass BigCrush in the Philox paper, 30 % fewer multiplies
+// two uniforms in [0,1) for (seed, event, index, domain), Philox4x32-10 (the time-bucket jitter has a generator of
+// its own, jitter_uniform() below)
 template <int ROUNDS = 10>
 __device__ __forceinline__ void rng_pair(uint64_t seed, uint64_t event, uint32_t index, uint32_t domain,
                                          double& ua, double& ub) {
@@ -68,6 +67,29 @@ __device__ __forceinline__ void rng_pair(uint64_t seed, uint64_t event, uint32_t
                      (uint32_t)(seed >> 32), r);
   ua = u53(r[0], r[1]);
   ub = u53(r[2], r[3]);
+}
+
+// The time-bucket jitter of a cloud point (simulator.py:108: tb += U[0, 1)), one draw per point and the most numerous
+// random numbers of the path, needs ONE uniform: Philox2x32-7 (Salmon et al., the 64-bit member of the family, 7 rounds
+// = the fewest that pass BigCrush in the paper; pinned by the Random123 known-answer vectors) -- one 32 x 32 -> 64
+// multiply per round where Philox4x32 has two.
+//   counter = (event[31:0], event[39:32] << 24 | key), key = tb << 14 | pad (24 bits);
+//   key word = seed[31:0] ^ rotl(seed[63:32], 13) ^ DOMAIN_JITTER;  U = u53(out0, out1).
+// A pure function of (seed, global event id, time bucket, pad), like every other draw; event ids 2^40 apart share
+// their jitter streams (nothing else).  The plain-C oracle and the host expansion of the 8-byte transfer record
+// (unpack_host.cpp) compute the identical value.
+__device__ __forceinline__ double jitter_uniform(uint32_t seed_lo, uint32_t seed_hi, uint32_t ev_lo, uint32_t ev_hi, uint32_t key) {
+  uint32_t c0 = ev_lo, c1 = (ev_hi << 24) | key;
+  uint32_t k = seed_lo ^ ((seed_hi << 13) | (seed_hi >> 19)) ^ DOMAIN_JITTER;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    uint32_t hi, lo;
+    mul_hi_lo(c0, 0xD256D193u, hi, lo);
+    c0 = hi ^ k ^ c1;
+    c1 = lo;
+    k += 0x9E3779B9u;
+  }
+  return u53(c0, c1);
 }
 
 // Box-Muller, cosine branch, on (1 - ua) in (0, 1]

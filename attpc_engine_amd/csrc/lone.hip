@@ -180,8 +180,7 @@ __global__ __launch_bounds__(LONE_THREADS) void lone_bucket_kernel(ScatterArgs a
       my_keys += (event << 24) + (unsigned long long)key;
       if (base != ~0ull) {
         const unsigned long long row = base + atomicAdd(&sh.cursor, 1u);
-        double ua, ub;
-        rng_pair<7>(a.seed, event, key, DOMAIN_JITTER, ua, ub);  // simulator.py:108
+        const double ua = jitter_uniform((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)event, (uint32_t)(event >> 32), key);  // simulator.py:108
         double* o = a.out.points + row * 3;
         o[0] = (double)pad;
         o[1] = (double)tb + ua;

@@ -1606,14 +1606,12 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           my_charge += q;
           my_keys += (((unsigned long long)ev_hi << 32 | ev_lo) << 24) + (unsigned long long)key;
           if (base != ~0ull) {
-            double ua, ub;
-            // The seed goes through an opaque asm per row: the 14 Philox round keys are then scalar adds inside
-            // the loop instead of 14 scalar registers held (and, at the limit of 102, spilled to vector lanes
+            // The seed goes through an opaque asm per row: the Philox round keys are then scalar adds inside
+            // the loop instead of scalar registers held (and, at the limit of 102, spilled to vector lanes
             // and read back with a VALU instruction each) across the whole kernel
             uint32_t seed_lo = (uint32_t)a.seed, seed_hi = (uint32_t)(a.seed >> 32);
             asm volatile("" : "+s"(seed_lo), "+s"(seed_hi));
-            rng_pair<7>((uint64_t)seed_lo | ((uint64_t)seed_hi << 32), (uint64_t)ev_lo | ((uint64_t)ev_hi << 32), key,
-                        DOMAIN_JITTER, ua, ub);  // simulator.py:108
+            const double ua = jitter_uniform(seed_lo, seed_hi, ev_lo, ev_hi, key);  // simulator.py:108
             prow[0] = (double)pad;
             prow[1] = (double)tb + ua;
             prow[2] = (double)q;

@@ -64,12 +64,65 @@ void unpack_spyral_slice(const SpyralPacked* src, int64_t lo, int64_t hi, Spyral
   }
 }
 
+void unpack8_slice(const unsigned long long* src, int64_t lo, int64_t hi, const int64_t* offsets, int64_t n_events,
+                   uint64_t seed, uint64_t first_event, double* points, int64_t* labels) {
+  if (lo >= hi) return;
+  // the event of row lo: the last e with offsets[e] - offsets[0] <= lo (events without rows are skipped over)
+  const int64_t base = offsets[0];
+  int64_t e = std::upper_bound(offsets, offsets + n_events + 1, lo + base) - offsets - 1;
+  int64_t e_end = offsets[e + 1] - base;
+  for (int64_t r = lo; r < hi; ++r) {
+    while (r >= e_end) {
+      ++e;
+      e_end = offsets[e + 1] - base;
+    }
+    const unsigned long long b = src[r];
+    const uint32_t tb = (uint32_t)((b >> PACK8_CHARGE_BITS) & ((1ull << PACK8_TB_BITS) - 1));
+    const uint32_t pad = (uint32_t)((b >> (PACK8_CHARGE_BITS + PACK8_TB_BITS)) & ((1ull << PACK_PAD_BITS) - 1));
+    const double u = jitter_uniform_host(seed, first_event + (uint64_t)e, (tb << 14) | pad);
+    nt_store((double)pad, &points[3 * r]);
+    nt_store((double)tb + u, &points[3 * r + 1]);  // simulator.py:108, as the kernel's flush computes it
+    nt_store((double)(b & ((1ull << PACK8_CHARGE_BITS) - 1)), &points[3 * r + 2]);
+    nt_store((long long)(b >> (PACK8_CHARGE_BITS + PACK8_TB_BITS + PACK_PAD_BITS)), reinterpret_cast<long long*>(&labels[r]));
+  }
+}
+
 int pick_threads(int n_threads, int64_t n, int64_t rows_per_thread) {
   if (n_threads <= 0) n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
   return (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n / rows_per_thread));
 }
 
 }  // namespace
+
+double jitter_uniform_host(uint64_t seed, uint64_t event, uint32_t key24) {
+  const uint32_t seed_lo = (uint32_t)seed, seed_hi = (uint32_t)(seed >> 32);
+  uint32_t c0 = (uint32_t)event, c1 = ((uint32_t)(event >> 32) << 24) | key24;
+  uint32_t k = seed_lo ^ ((seed_hi << 13) | (seed_hi >> 19)) ^ 0x100u;
+  for (int r = 0; r < 7; ++r) {  // Philox2x32-7
+    const uint64_t p = (uint64_t)0xD256D193u * (uint64_t)c0;
+    const uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
+    c1 = (uint32_t)p;
+    c0 = n0;
+    k += 0x9E3779B9u;
+  }
+  return ((double)(c0 >> 5) * 67108864.0 + (double)(c1 >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+void unpack_rows8(const unsigned long long* src, int64_t n, const int64_t* offsets, int64_t n_events, uint64_t seed,
+                  uint64_t first_event, double* points, int64_t* labels, int n_threads) {
+  n_threads = pick_threads(n_threads, n, 32768);
+  if (n_threads <= 1) {
+    unpack8_slice(src, 0, n, offsets, n_events, seed, first_event, points, labels);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const int64_t per = (n + n_threads - 1) / n_threads;
+  for (int t = 1; t < n_threads; ++t)
+    pool.emplace_back(unpack8_slice, src, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per), offsets, n_events, seed,
+                      first_event, points, labels);
+  unpack8_slice(src, 0, std::min<int64_t>(n, per), offsets, n_events, seed, first_event, points, labels);
+  for (std::thread& th : pool) th.join();
+}
 
 void unpack_rows(const PackedRow* src, int64_t n, double* points, int64_t* labels, int n_threads) {
   n_threads = pick_threads(n_threads, n, 65536);

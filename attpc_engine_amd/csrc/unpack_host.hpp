@@ -15,6 +15,14 @@ struct PackedRow {
 };
 constexpr int PACK_CHARGE_BITS = 45, PACK_PAD_BITS = 14;
 
+// The 8-byte record of a cloud row: the jitter is a pure function of (seed, global event id, time bucket, pad)
+// (csrc/common.hpp jitter_uniform: Philox2x32-7), so it need not cross the link at all --
+//   electrons (36 bits) | time bucket << 36 (9) | pad << 45 (14) | label << 59 (5),
+// and the host rebuilds column 1 as (double)tb + jitter_uniform(...) with the kernel's own operations: bit-identical.
+constexpr int PACK8_CHARGE_BITS = 36, PACK8_TB_BITS = 9;
+// the same function as the device's jitter_uniform() (and the oracle's orc_jitter_uniform)
+double jitter_uniform_host(uint64_t seed, uint64_t event, uint32_t key24);
+
 // Compact transfer record of a Spyral row (24 instead of 72 bytes; the host rebuilds x, y, z, amplitude and pad
 // scale from it): time bucket + jitter, electrons | pad << 45 | label << 59, clipped integral.
 struct SpyralPacked {
@@ -35,5 +43,9 @@ struct SpyralHostTables {  // what convert_to_spyral (writer.py:61-112) needs be
 void unpack_rows(const PackedRow* src, int64_t n, double* points, int64_t* labels, int n_threads);
 void unpack_spyral_rows(const SpyralPacked* src, int64_t n, const SpyralHostTables& t, double* rows, int64_t* labels,
                         int n_threads);
+// rows of events first_event .. first_event + n_events - 1 in event order; offsets [n_events + 1] = CSR offsets of the
+// events inside src (offsets[n_events] - offsets[0] == n; only differences are used)
+void unpack_rows8(const unsigned long long* src, int64_t n, const int64_t* offsets, int64_t n_events, uint64_t seed,
+                  uint64_t first_event, double* points, int64_t* labels, int n_threads);
 
 }  // namespace attpc

@@ -55,6 +55,14 @@ class Engine:
         self._out_cache = (key, arrays) if reuse else None
         return arrays
 
+    def hint_next(self, n_events: int, seed: int = 0, first_event: int = 0) -> None:
+        """Announce the ``run`` / ``run_spyral`` call after the next one (``attpc_sim_hint_next``): the next call then
+        queues that call's first kinematics + track batch behind its own last scatter launches.  A scheduling hint
+        only -- results never depend on it; ``n_events = 0`` withdraws it."""
+        ctx = self.ctx
+        ctx.check(ctx.lib.attpc_sim_hint_next(ctx.handle, int(seed), int(first_event), int(n_events), self.layout),
+                  "attpc_sim_hint_next")
+
     def run(self, n_events: int, seed: int = 0, first_event: int = 0, fetch: bool = False,
             capacity_per_event: int = 12288, pinned: bool = False, reuse_buffers: bool = False) -> dict:
         """Simulate events ``first_event .. first_event + n_events - 1``.

@@ -190,6 +190,12 @@ def main(argv=None) -> int:
     my_events = 0
     for step in range(args.steps):
         first, n = step_range(step)
+        if step + 1 < args.steps and hasattr(engine, "hint_next"):
+            # a stream of calls: say what the next one will be, so that its first track batch is integrated behind
+            # this call's last scatter launches.  Never across the edges of the timed region: the last warm-up step
+            # announces nothing (step 0 does all of its own work in here), and the last timed step neither.
+            nxt_first, nxt_n = step_range(step + 1)
+            engine.hint_next(nxt_n, seed=args.seed, first_event=nxt_first)
         stats = engine.run(n, seed=args.seed, first_event=first)["stats"]
         my_events += n
         for k in agg:

@@ -15,9 +15,11 @@
  *     attpc_ctx_destroy.  A ctx is single-threaded; distinct ctxs (one per GPU,
  *     one per process in the multi-GPU bench) are independent.
  *   - all floating point is IEEE binary64 ("f64"), charges are int64.
- *   - random numbers: Philox4x32-10 (Philox4x32-7 for the time-bucket jitter of the
- *     cloud points), key = seed, counter = (global event id, draw index, domain)
- *     -- results do not depend on batch/chunk/GPU count.
+ *   - random numbers: Philox4x32-10, key = seed, counter = (global event id, draw index, domain); the
+ *     time-bucket jitter of a cloud point is Philox2x32-7 with counter = (event[31:0],
+ *     event[39:32] << 24 | tb << 14 | pad) and key word = seed[31:0] ^ rotl(seed[63:32], 13) ^ 0x100
+ *     -- every draw a pure function of (seed, global event id, ...): results do not depend on
+ *     batch / chunk / GPU count.
  */
 #ifndef ATTPC_ENGINE_H
 #define ATTPC_ENGINE_H
@@ -217,9 +219,12 @@ ATTPC_API int32_t attpc_sync(attpc_ctx* ctx);
  *                      one-workgroup build of the scatter kernel
  *   "tiny_buffers"     != 0: the next buffers are allocated far too small (exercises the
  *                      grow-and-rerun path in tests)
- *   "compact_transfer" != 0 (default): delivered clouds cross PCIe as 16-byte records (attpc_unpack_rows) into
- *                      library-owned pinned staging and are expanded into the caller's arrays by host threads;
- *                      0: rows are copied in the reference's dtypes (32 bytes) straight into the caller's arrays
+ *   "compact_transfer" 2 (default): delivered clouds cross PCIe as 8-byte records (attpc_unpack_rows8: the host
+ *                      regenerates the time-bucket jitter), 1: as 16-byte records (attpc_unpack_rows), into
+ *                      library-owned pinned staging, and are expanded into the caller's arrays by host threads; a chunk
+ *                      with a row that does not fit the record falls back to the next wider form;
+ *                      0: rows are copied in the reference's dtypes (32 bytes) straight into the caller's arrays.
+ *                      Spyral rows: != 0 = 24-byte records (attpc_unpack_spyral_rows)
  *   "unpack_threads"   host threads of that expansion; 0 (default) = min(16, hardware threads)
  *   "deliver_chunk_events"  events per chunk when clouds are delivered (default 8192: a chunk's copy hides the next
  *                      chunk's scatter and assembly; the first chunk's device work and the last chunk's expansion
@@ -240,6 +245,16 @@ ATTPC_API int32_t attpc_host_free(attpc_ctx* ctx, void* ptr);
  *   bytes 8..15  u64  electrons (bits 0..44) | pad << 45 (14 bits) | label << 59 (5 bits)
  * -> points[r] = (pad, time bucket, electrons) as f64, labels[r] as i64 (detector/simulator.py:40-46). */
 ATTPC_API int32_t attpc_unpack_rows(const void* packed, int64_t n_rows, double* points, int64_t* labels, int32_t n_threads);
+/* The 8-byte transfer record of a cloud row ("compact_transfer" 2, the default) and its expansion, host only.  The
+ * jitter of a cloud point is a pure function of (seed, global event id, time bucket, pad) -- Philox2x32-7, see the
+ * conventions at the top -- so it does not cross the link: the host regenerates it.
+ *   u64  electrons (bits 0..35) | time bucket << 36 (9 bits) | pad << 45 (14 bits) | label << 59 (5 bits)
+ * packed [n_rows] holds the rows of events first_event .. first_event + n_events - 1 in event order, offsets
+ * [n_events + 1] their CSR offsets (offsets[n_events] - offsets[0] == n_rows)
+ * -> points[r] = (pad, time bucket + jitter, electrons) as f64, labels[r] as i64: bit-identical to the rows the device
+ * writes (detector/simulator.py:40-46, :108). */
+ATTPC_API int32_t attpc_unpack_rows8(const void* packed, int64_t n_rows, const int64_t* offsets, int64_t n_events,
+                                     uint64_t seed, uint64_t first_event, double* points, int64_t* labels, int32_t n_threads);
 /* The 24-byte transfer record of a Spyral row (attpc_sim_run_spyral with "compact_transfer") and its expansion
  * to the 8 columns of convert_to_spyral (detector/writer.py:61-112), host only:
  *   bytes 0..7 f64 time bucket + jitter, 8..15 u64 electrons | pad << 45 | label << 59, 16..23 f64 clipped integral
@@ -295,6 +310,17 @@ ATTPC_API int32_t attpc_det_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_ev
 ATTPC_API int32_t attpc_sim_run(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
                       const attpc_event_layout* layout, double* p4, double* vertex,
                       int32_t* kin_status, attpc_cloud_out* out, attpc_run_stats* stats);
+
+/* Announces the attpc_sim_run / attpc_sim_run_spyral call AFTER the next one: "when the run I am about to start has
+ * queued its last track batch, go on with the kinematics + tracks of events first_event .. of this seed".  The next
+ * run then queues that first batch (up to 8 scatter chunks) on its low-priority stream behind its own last scatter
+ * launches, and the call that was announced finds it under way instead of starting with track integration that has
+ * nothing to run beside (about 5 % of a 1e6-event call of the headline workload).  Purely a scheduling hint: a call
+ * for other events, another entry point or a configure call lets the batch finish and drops it; results never depend
+ * on it.  n_events == 0 or layout == NULL withdraws the announcement.  The reference has no counterpart (its loop is
+ * one event at a time, detector/simulator.py:183-208). */
+ATTPC_API int32_t attpc_sim_hint_next(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t n_events,
+                                      const attpc_event_layout* layout);
 
 /* Diagnostics used by the parity tests: one track per (event, simulated nucleus) of a
  * det_run-style input.  samples [n_tracks, ATTPC_TIME_SAMPLES, 4] rows (x m, y m,

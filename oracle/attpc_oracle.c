@@ -63,15 +63,30 @@ void orc_rng_pair(uint64_t seed, uint64_t event, uint32_t index, uint32_t domain
   *u_b = u53(r[2], r[3]);
 }
 
-/* the time-bucket jitter (one draw per cloud point, the most numerous random numbers of the path)
- * uses the 7-round variant: the fewest rounds that pass BigCrush in the Philox paper */
-void orc_rng_pair7(uint64_t seed, uint64_t event, uint32_t index, uint32_t domain, double* u_a, double* u_b) {
-  uint32_t ctr[4] = {(uint32_t)event, (uint32_t)(event >> 32), index, domain};
-  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  uint32_t r[4];
-  orc_philox4x32(ctr, key, 7, r);
-  *u_a = u53(r[0], r[1]);
-  *u_b = u53(r[2], r[3]);
+/* Philox2x32 (Salmon et al. SC'11), the 64-bit member of the family; pinned by the Random123 known-answer vectors
+ * (tests/test_oracle_golden.py). */
+void orc_philox2x32(const uint32_t ctr_in[2], uint32_t key, int32_t rounds, uint32_t out[2]) {
+  uint32_t c0 = ctr_in[0], c1 = ctr_in[1], k = key;
+  for (int32_t r = 0; r < rounds; ++r) {
+    uint64_t p = (uint64_t)0xD256D193u * (uint64_t)c0;
+    uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
+    c1 = (uint32_t)p;
+    c0 = n0;
+    k += 0x9E3779B9u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+}
+
+/* the time-bucket jitter of a cloud point (simulator.py:108: tb += U[0,1); one draw per point, the most numerous
+ * random numbers of the path): Philox2x32-7 -- the fewest rounds that pass BigCrush in the Philox paper --
+ * counter = (event[31:0], event[39:32] << 24 | tb << 14 | pad), key = seed[31:0] ^ rotl(seed[63:32], 13) ^ 0x100 */
+double orc_jitter_uniform(uint64_t seed, uint64_t event, uint32_t key24) {
+  uint32_t seed_lo = (uint32_t)seed, seed_hi = (uint32_t)(seed >> 32);
+  uint32_t ctr[2] = {(uint32_t)event, ((uint32_t)(event >> 32) << 24) | key24};
+  uint32_t r[2];
+  orc_philox2x32(ctr, seed_lo ^ ((seed_hi << 13) | (seed_hi >> 19)) ^ 0x100u, 7, r);
+  return u53(r[0], r[1]);
 }
 
 /* Box-Muller on (1-u_a) in (0,1] and u_b */
@@ -666,8 +681,8 @@ int32_t orc_generate_point_cloud(const orc_det_desc* det, const orc_species_desc
   return generate_point_cloud_ex(det, sp, mom, vertex, seed, event, label, points, samples_out, n_track_rows, 0);
 }
 
-/* detector/simulator.py:52-115 (+ dict_to_points :19-49).  The tb jitter of a point is the
- * Philox4x32-7 uniform with index (tb<<14 | pad) in domain 0x100 of the event. */
+/* detector/simulator.py:52-115 (+ dict_to_points :19-49).  The tb jitter of a point is
+ * orc_jitter_uniform(seed, event, tb << 14 | pad). */
 int64_t orc_simulate(const orc_det_desc* det, const orc_event_layout* lay, uint64_t seed, uint64_t event,
                      const double* p4, const double* vertex, int64_t capacity, double* points,
                      int64_t* labels, uint64_t* n_track_samples) {
@@ -687,9 +702,7 @@ int64_t orc_simulate(const orc_det_desc* det, const orc_event_layout* lay, uint6
     orc_unpair(d->keys[i], &tb, &pad);
     double tbf = (double)tb;
     if (tb >= 0 && pad >= 0) {
-      double ua, ub;
-      orc_rng_pair7(seed, event, (uint32_t)((tb << 14) | pad), 0x100u, &ua, &ub);
-      tbf += ua; /* simulator.py:108 */
+      tbf += orc_jitter_uniform(seed, event, (uint32_t)((tb << 14) | pad)); /* simulator.py:108 */
     }
     if (0.0 <= tbf && tbf < (double)ORC_NUM_TB) { /* simulator.py:111-113 */
       if (n_out < capacity) {

@@ -88,7 +88,8 @@ typedef struct {
 /* RNG */
 void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int32_t rounds, uint32_t out[4]);
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-void orc_rng_pair7(uint64_t seed, uint64_t event, uint32_t index, uint32_t domain, double* u_a, double* u_b);
+void orc_philox2x32(const uint32_t ctr_in[2], uint32_t key, int32_t rounds, uint32_t out[2]);
+double orc_jitter_uniform(uint64_t seed, uint64_t event, uint32_t key24);
 void orc_rng_pair(uint64_t seed, uint64_t event, uint32_t index, uint32_t domain, double* u_a,
                   double* u_b);
 double orc_rng_normal(uint64_t seed, uint64_t event, uint32_t index, uint32_t domain);

@@ -42,6 +42,10 @@ def lib() -> C.CDLL:
     L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.orc_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_uint32)]
     L.orc_rng_pair.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _dp, _dp]
+    L.orc_philox2x32.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_int32, C.POINTER(C.c_uint32)]
+    L.orc_philox2x32.restype = None
+    L.orc_jitter_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+    L.orc_jitter_uniform.restype = C.c_double
     L.orc_rng_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     L.orc_rng_normal.restype = C.c_double
     L.orc_reaction_allowed.argtypes = [_dp, C.c_double, C.c_double]
@@ -107,6 +111,17 @@ def philox(ctr, key, rounds: int = 10) -> np.ndarray:
     out = (C.c_uint32 * 4)()
     lib().orc_philox4x32(c, k, int(rounds), out)
     return np.array(list(out), dtype=np.uint32)
+
+
+def philox2x32(ctr, key: int, rounds: int = 10) -> np.ndarray:
+    c = (C.c_uint32 * 2)(*[int(v) for v in ctr])
+    out = (C.c_uint32 * 2)()
+    lib().orc_philox2x32(c, C.c_uint32(int(key)), int(rounds), out)
+    return np.array(list(out), dtype=np.uint32)
+
+
+def jitter_uniform(seed: int, event: int, key24: int) -> float:
+    return float(lib().orc_jitter_uniform(int(seed), int(event), int(key24)))
 
 
 def kin_calculate(desc: _abi.KinDesc, beam, ex, th, ph):

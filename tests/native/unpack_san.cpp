@@ -72,6 +72,40 @@ int main(int argc, char** argv) {
       free(labels);
     }
   }
+  {  // 8-byte records: the host regenerates the jitter; events of ragged sizes, some empty
+    const long long n_events = 997;
+    std::vector<int64_t> offsets(n_events + 1, 0);
+    for (long long e = 0; e < n_events; ++e) {
+      long long c = (long long)(lcg(seed) % (2 * n / n_events));
+      if (e % 50 == 3) c = 0;
+      offsets[e + 1] = offsets[e] + c;
+    }
+    const long long m = offsets[n_events] < n ? offsets[n_events] : n;
+    for (long long e = 0; e <= n_events; ++e) offsets[e] = offsets[e] > m ? m : offsets[e];
+    std::vector<unsigned long long> rows8(m);
+    std::vector<long long> ev_of(m);
+    for (long long e = 0; e < n_events; ++e)
+      for (long long r = offsets[e]; r < offsets[e + 1]; ++r) ev_of[r] = e;
+    for (long long r = 0; r < m; ++r) {
+      const unsigned long long q = lcg(seed) & ((1ull << PACK8_CHARGE_BITS) - 1), tb = lcg(seed) % 512;
+      rows8[r] = q | (tb << PACK8_CHARGE_BITS) | ((unsigned long long)want_pad[r] << (PACK8_CHARGE_BITS + PACK8_TB_BITS)) |
+                 ((unsigned long long)want_label[r] << (PACK8_CHARGE_BITS + PACK8_TB_BITS + PACK_PAD_BITS));
+    }
+    for (int threads : {1, 4, 16}) {
+      double* points = (double*)malloc((size_t)(3 * m + 1) * sizeof(double));
+      long long* labels = (long long*)malloc((size_t)(m + 1) * sizeof(long long));
+      unpack_rows8(rows8.data(), m, offsets.data(), n_events, 77ull, 1000000ull, points, (int64_t*)labels, threads);
+      for (long long r = 0; r < m; ++r) {
+        const unsigned long long b = rows8[r];
+        const unsigned tb = (unsigned)((b >> PACK8_CHARGE_BITS) & 511u);
+        const double u = jitter_uniform_host(77ull, 1000000ull + (unsigned long long)ev_of[r], (tb << 14) | (unsigned)want_pad[r]);
+        bad += points[3 * r] != (double)want_pad[r] || points[3 * r + 1] != (double)tb + u ||
+               points[3 * r + 2] != (double)(b & ((1ull << PACK8_CHARGE_BITS) - 1)) || labels[r] != want_label[r];
+      }
+      free(points);
+      free(labels);
+    }
+  }
   printf("unpack_san: %lld rows, mismatches %lld\n", n, bad);
   return bad ? 1 : 0;
 }

@@ -401,21 +401,61 @@ def test_multichunk_assembly_and_buffer_growth(orc):
     fresh.close()
 
 
-@pytest.mark.parametrize("name,n", [("o16aa", 4000), ("be10dp", 4000)])
+@pytest.mark.parametrize("name,n", [("o16aa", 50_000), ("be10dp", 50_000), ("b10chain", 1_500)])
 def test_bulk_checksums_vs_oracle(ctx, orc, name, n):
-    """A few thousand events, statistics only: the number of cloud points, of kept track samples
-    and the checksum over every (event, time bucket, pad) key equal the oracle's exactly; the
-    charge checksums agree to within the per-point tolerance."""
+    """Tens of thousands of events (about 15 s of the oracle on the box's host threads each; b10chain = BASELINE
+    configs[4] as written: 0.1 mm path step, 10x diffusion, through the scatter kernel's merge variant), statistics
+    only: the number of cloud points, of kept track samples and the checksum over every (event, time bucket, pad) key
+    equal the oracle's exactly; the charge checksums agree to within the per-point tolerance."""
+    import os
     inp = Inputs(name)
     eng = _engine(inp, ctx)
     st = eng.run(n, seed=2024, first_event=100)["stats"]
-    ref = orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=2024, first=100, n=n, threads=32)["stats"]
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    ref = orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=2024, first=100, n=n, threads=threads)["stats"]
     assert st["n_points"] == ref[0] and st["n_track_samples"] == ref[1]
     assert st["key_checksum"] == ref[3] % (1 << 64)
     diff = (int(st["charge_checksum"]) - int(ref[2] % (1 << 64)) + (1 << 63)) % (1 << 64) - (1 << 63)
-    assert abs(diff) <= 2 * max(8, st["n_points"] // 10_000), diff  # see test_sim_run_vs_oracle
+    # Two kinds of last-bit effects (DESIGN.md section 6): (i) int(pdf h^2 n) of a pixel flips by one electron where
+    # device exp/multiply and glibc differ in the last bit -- at most 2 electrons per 10 000 points; (ii) the Fano draw
+    # trunc(mu + sigma z) of a track sample flips by one PRIMARY electron where device log / sincos and glibc differ
+    # in the last bit of z -- about one sample in 1e7..1e8; it moves the event's charge by one electron x the gain
+    # (175 000).  First seen at this size: 1 such sample in 2.5e7 (o16aa, 50 000 events: checksum off by 171 355).
+    gain = int(inp.config.det_params.mpgd_gain)
+    fano_flips_allowed = 2 + st["n_track_samples"] // 5_000_000
+    assert abs(diff) <= 2 * max(8, st["n_points"] // 10_000) + fano_flips_allowed * gain, diff
     assert st["n_failed"] == 0 and st["n_inconsistent"] == 0
-    print(name, "points", st["n_points"], "charge checksum difference (electrons)", diff)
+    print(name, "events", n, "points", st["n_points"], "charge checksum difference (electrons)", diff,
+          "lone buckets", st["n_lone_buckets"], "retried windows", st["n_lds_overflow"], "capped tracks", st["n_tracks_capped"])
+
+
+def test_delivered_run_after_a_resident_run_sizes_its_buffers_by_its_own_chunks():
+    """A device-resident run of a heavy workload leaves a cloud buffer of many GB (chunks of ~13 000 events of
+    54 k points); a delivered run behind it works in chunks of a few hundred events and must size its assembly sets,
+    transfer records and Spyral scratch by THOSE (launch_row_cap), not by the buffer it finds -- round 2 asked the
+    allocator for 200 GB here (bench.py --workload b10chain, delivered leg).  Pinned on the context's own account of
+    the device memory it holds."""
+    fresh = _abi.Context(0)
+    try:
+        inp = Inputs("b10chain")
+        eng = _engine(inp, fresh)
+        resident = eng.run(12_000, seed=4)["stats"]
+        assert resident["n_failed"] == 0 and resident["device_bytes"] > 4 << 30  # the big cloud buffer is there
+        n = 500
+        res = eng.run(n, seed=4, first_event=0, fetch=True, capacity_per_event=70_000)
+        st = res["stats"]
+        rows = st["n_points"]
+        assert res["offsets"][-1] == rows and rows > 20_000 * n
+        grown = st["device_bytes"] - resident["device_bytes"]
+        # two assembly sets of at most this call's rows: event-ordered points (24 B) + labels (8 B) + 16-byte transfer
+        # records per row, 12 % headroom, a 25 % growth step; plus offsets and control words
+        bound = 2 * rows * (24 + 8 + 16) * 1.12 * 1.25 + (256 << 20)
+        assert grown < bound, (grown, bound, resident["device_bytes"])
+        again = eng.run(n, seed=4, first_event=n, fetch=True, capacity_per_event=70_000)["stats"]
+        assert again["device_bytes"] - st["device_bytes"] < (64 << 20) and again["n_buffer_growths"] <= 4
+        print("device bytes: resident run", resident["device_bytes"], "+ delivered run", grown, "bound", int(bound))
+    finally:
+        fresh.close()
 
 
 # ---------------------------------------------------------------- size-independent properties
@@ -538,15 +578,14 @@ def test_merge_variant_vs_oracle(orc, name, n, kw, det_kw):
 def test_merge_variant_checksums_equal_the_default_kernel():
     """Same events through the default kernel and the merge variant (both table sizes): identical point counts and
     key checksums, charge checksums equal (integer sums of the same truncated terms, regrouped)."""
-    for name, n, kw in (("b10chain", 400, {}), ("o16aa", 3000, {}), ("o16aa", 600, {"path_step": 2.0e-4})):
+    for name, n, kw in (("b10chain", 200, {}), ("o16aa", 1500, {}), ("o16aa", 400, {"path_step": 2.0e-4})):
         got = {}
-        for variant in (2, 1):
-            for merge in (0, 1):
-                fresh = _abi.Context(0)
-                fresh.set_option("scatter_variant", variant)
-                fresh.set_option("scatter_merge", merge)
-                got[variant, merge] = _engine(Inputs(name, **kw), fresh).run(n, seed=8, first_event=21)["stats"]
-                fresh.close()
+        for variant, merge in ((2, 0), (2, 1), (1, 1)):
+            fresh = _abi.Context(0)
+            fresh.set_option("scatter_variant", variant)
+            fresh.set_option("scatter_merge", merge)
+            got[variant, merge] = _engine(Inputs(name, **kw), fresh).run(n, seed=8, first_event=21)["stats"]
+            fresh.close()
         base = got[2, 0]
         assert base["n_points"] > 0 and base["n_failed"] == 0
         for key, st in got.items():
@@ -554,6 +593,51 @@ def test_merge_variant_checksums_equal_the_default_kernel():
                 assert st[k] == base[k], (name, key, k, st[k], base[k])
         print(name, kw, "points", base["n_points"], "retried windows default / merge (big):",
               got[2, 0]["n_lds_overflow"], got[2, 1]["n_lds_overflow"])
+
+
+def test_hint_next_is_only_a_scheduling_hint():
+    """attpc_sim_hint_next lets a run queue the NEXT call's first track batch behind its own last scatter launches.
+    Results never depend on it: announced and taken up, announced and not taken up (other events, another entry
+    point, a new configuration in between), not announced -- always the same clouds."""
+    fresh = _abi.Context(0)
+    try:
+        inp = Inputs("o16aa")
+        eng = _engine(inp, fresh, chunk_events=1024)
+        n = 2500
+        plain_a = eng.run(n, seed=6, first_event=0)["stats"]
+        plain_b = eng.run(n, seed=6, first_event=n)["stats"]
+        keys = ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_failed", "n_inconsistent")
+        # announced and taken up
+        eng.hint_next(n, seed=6, first_event=n)
+        a = eng.run(n, seed=6, first_event=0)["stats"]
+        b = eng.run(n, seed=6, first_event=n, fetch=True)
+        for k in keys:
+            assert a[k] == plain_a[k] and b["stats"][k] == plain_b[k], k
+        assert b["stats"]["launches_tracks"] == plain_b["launches_tracks"]
+        assert int(b["points"][:, 2].astype(np.uint64).sum(dtype=np.uint64)) == plain_b["charge_checksum"]
+        # announced, then something else comes: other events / the file-driven entry point / a configure call
+        eng.hint_next(n, seed=6, first_event=n)
+        eng.run(n, seed=6, first_event=0)
+        other = eng.run(n, seed=6, first_event=7 * n)["stats"]
+        assert other["key_checksum"] != plain_b["key_checksum"] and other["n_failed"] == 0
+        eng.hint_next(n, seed=6, first_event=n)
+        eng.run(n, seed=6, first_event=0)
+        from attpc_engine_amd.detector.simulator import simulate_batch
+        inp.pipeline._ctx = fresh
+        vertex, p4 = inp.pipeline.run_many(16, first_event=0, seed=6)
+        off, pts, lab, st = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, 6, inp.indices, ctx=fresh)
+        assert st["n_failed"] == 0 and off[-1] > 0
+        eng2 = _engine(inp, fresh, chunk_events=1024)      # configures again
+        eng2.hint_next(n, seed=6, first_event=n)
+        eng2.run(n, seed=6, first_event=0)
+        eng3 = _engine(Inputs("be10dp"), fresh)            # another workload while a batch is queued ahead
+        be = eng3.run(2000, seed=6, first_event=0)["stats"]
+        assert be["n_failed"] == 0 and be["n_points"] > 0
+        again = _engine(inp, fresh, chunk_events=1024).run(n, seed=6, first_event=n)["stats"]
+        for k in keys:
+            assert again[k] == plain_b[k], k
+    finally:
+        fresh.close()
 
 
 def test_fetch_with_block_reserved_rows(ctx):
@@ -951,16 +1035,17 @@ def test_assembly_insert_loop_equals_the_compiled_one():
     import sys
 
     root = Path(__file__).resolve().parents[1]
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not Path(hipcc).exists():
-        pytest.skip("hipcc not available to build the comparison library")
+    sys.path.insert(0, str(root))
+    import __graft_entry__ as graft
     variant = root / "attpc_engine_amd" / "_lib" / "libattpc_test_cxxinsert.so"
-    csrc = root / "attpc_engine_amd" / "csrc"
-    sources = [csrc / n for n in ("abi.hip", "kinematics.hip", "tracks.hip", "scatter.hip", "scatter_small.hip", "lone.hip", "spyral.hip")]
-    if not variant.exists() or any(s.stat().st_mtime > variant.stat().st_mtime for s in sources):
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-                        "-DATTPC_SC_CXX_INSERT", f"-I{root / 'include'}", f"-I{csrc}", "-o", str(variant)] + [str(s) for s in sources],
-                       check=True, capture_output=True)
+    if graft._stale(variant, [graft.CSRC / n for n in graft.HIP_SOURCES + graft.HOST_SOURCES] +
+                    [graft.CSRC / "common.hpp", graft.CSRC / "tracks_args.hpp", graft.CSRC / "unpack_host.hpp",
+                     root / "include" / "attpc_engine.h"],
+                    ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
+                     "-Wno-unused-function", "-DATTPC_SC_CXX_INSERT"]):
+        if shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists():
+            pytest.skip("comparison library is not current and hipcc is not available to build it")
+        graft.build()  # one recipe for both libraries (decided on source content: a pushed snapshot does not rebuild)
     shipped = root / "attpc_engine_amd" / "_lib" / "libattpc_hip.so"
     out = {}
     for tag, lib in (("asm", shipped), ("cxx", variant)):

@@ -292,6 +292,57 @@ def test_transfer_record_unpack():
     assert lib.attpc_unpack_rows(None, 0, None, None, 1) == 0
 
 
+def test_tight_transfer_record_unpack_regenerates_the_jitter():
+    """The 8-byte transfer record of a cloud row (attpc_unpack_rows8): the time-bucket jitter is not in the record,
+    the host regenerates it from (seed, global event id, time bucket, pad) -- checked against the oracle's
+    orc_jitter_uniform (itself pinned to the Random123 Philox2x32 vectors) for ragged events, empty events, all
+    field extremes and several thread counts.  Pure host code: runs without a GPU."""
+    import ctypes as C
+    from oracle import pyoracle as orc
+    lib = _abi.load_library()
+    rng = np.random.default_rng(11)
+    n_events = 700
+    counts = rng.integers(0, 900, size=n_events)
+    counts[[0, 5, 6, n_events - 1]] = 0          # empty events at the ends and in a row
+    counts[100] = 70_000                          # one event across several thread slices
+    offsets = np.zeros(n_events + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    offsets += 12345                              # only differences count
+    n = int(counts.sum())
+    pad = rng.integers(0, 1 << 14, size=n).astype(np.uint64)
+    label = rng.integers(0, 32, size=n).astype(np.uint64)
+    charge = rng.integers(0, 1 << 36, size=n, dtype=np.uint64)
+    tb = rng.integers(0, 512, size=n).astype(np.uint64)
+    pad[:4] = [0, (1 << 14) - 1, 0, (1 << 14) - 1]
+    label[:4] = [0, 31, 31, 0]
+    charge[:4] = [0, (1 << 36) - 1, 0, (1 << 36) - 1]
+    tb[:4] = [0, 511, 511, 0]
+    packed = charge | (tb << np.uint64(36)) | (pad << np.uint64(45)) | (label << np.uint64(59))
+    seed, first = 0xFEDCBA9876543210 & ((1 << 63) - 1), (1 << 33) + 17   # event ids beyond 32 bits
+    event_of_row = np.repeat(np.arange(n_events), counts)
+    check = np.unique(np.concatenate([np.arange(0, 2000), rng.integers(0, n, 4000), np.arange(n - 500, n)]))
+    want_jitter = np.array([orc.jitter_uniform(seed, first + int(event_of_row[r]), (int(tb[r]) << 14) | int(pad[r])) for r in check])
+    for threads in (1, 0, 5):
+        points = np.full((n, 3), -1.0)
+        labels = np.full(n, -1, dtype=np.int64)
+        rc = lib.attpc_unpack_rows8(packed.ctypes.data_as(C.c_void_p), n, _abi.iptr(offsets, C.c_int64), n_events, seed, first,
+                                    _abi.dptr(points), _abi.iptr(labels, C.c_int64), threads)
+        assert rc == 0
+        np.testing.assert_array_equal(points[:, 0], pad.astype(np.float64))
+        np.testing.assert_array_equal(np.floor(points[:, 1]), tb.astype(np.float64))
+        np.testing.assert_array_equal(points[check, 1], tb[check].astype(np.float64) + want_jitter)
+        np.testing.assert_array_equal(points[:, 2], charge.astype(np.float64))
+        np.testing.assert_array_equal(labels, label.astype(np.int64))
+        if threads == 1:
+            first_pass = points.copy()
+        else:
+            np.testing.assert_array_equal(points, first_pass)   # independent of the slicing
+    bad = offsets.copy()
+    bad[-1] += 1
+    assert lib.attpc_unpack_rows8(packed.ctypes.data_as(C.c_void_p), n, _abi.iptr(bad, C.c_int64), n_events, seed, first,
+                                  _abi.dptr(points), _abi.iptr(labels, C.c_int64), 1) == _abi.E_INVALID
+
+
 def test_spyral_transfer_record_unpack(golden_dir):
     """attpc_unpack_spyral_rows against convert_to_spyral (the oracle's restatement, itself pinned to the rows the
     reference's own writer.convert_to_spyral made, tests/golden/response.npz): the 24-byte record holds (tb,

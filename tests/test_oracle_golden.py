@@ -19,11 +19,37 @@ def test_philox_known_answers():
     assert list(orc.philox([ones] * 4, [ones] * 2)) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
     assert list(orc.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0])) == [
         0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
-    # ... and for philox4x32-7 (the time-bucket jitter)
+    # ... philox4x32-7
     assert list(orc.philox([0, 0, 0, 0], [0, 0], 7)) == [0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48]
     assert list(orc.philox([ones] * 4, [ones] * 2, 7)) == [0x5207DDC2, 0x45165E59, 0x4D8EE751, 0x8C52F662]
     assert list(orc.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0], 7)) == [
         0x4DFCCABA, 0x190A87F0, 0xC47362BA, 0xB6B5242A]
+    # ... philox2x32-10 and philox2x32-7 (the 64-bit member of the family: the time-bucket jitter of the cloud points)
+    assert list(orc.philox2x32([0, 0], 0, 10)) == [0xFF1DAE59, 0x6CD10DF2]
+    assert list(orc.philox2x32([ones, ones], ones, 10)) == [0x2C3F628B, 0xAB4FD7AD]
+    assert list(orc.philox2x32([0x243F6A88, 0x85A308D3], 0x13198A2E, 10)) == [0xDD7CE038, 0xF62A4C12]
+    assert list(orc.philox2x32([0, 0], 0, 7)) == [0x257A3673, 0xCD26BE2A]
+    assert list(orc.philox2x32([ones, ones], ones, 7)) == [0xAB302C4D, 0x3DC9D239]
+
+
+def test_jitter_uniform_is_the_documented_function_of_seed_event_key():
+    """orc_jitter_uniform = u53 of Philox2x32-7 with counter (event[31:0], event[39:32] << 24 | key) and key word
+    seed[31:0] ^ rotl(seed[63:32], 13) ^ 0x100 -- the definition in csrc/common.hpp (jitter_uniform) restated in
+    numpy integers; uniform on [0, 1)."""
+    rng = np.random.default_rng(1)
+    vals = []
+    for _ in range(2000):
+        seed, event = int(rng.integers(0, 1 << 63)), int(rng.integers(0, 1 << 40))
+        key = int(rng.integers(0, 1 << 24))
+        seed_lo, seed_hi = seed & 0xFFFFFFFF, seed >> 32
+        word = seed_lo ^ (((seed_hi << 13) | (seed_hi >> 19)) & 0xFFFFFFFF) ^ 0x100
+        r = orc.philox2x32([event & 0xFFFFFFFF, (((event >> 32) << 24) & 0xFFFFFFFF) | key], word, 7)
+        want = ((int(r[0]) >> 5) * 67108864 + (int(r[1]) >> 6)) / 9007199254740992.0
+        got = orc.jitter_uniform(seed, event, key)
+        assert got == want and 0.0 <= got < 1.0
+        vals.append(got)
+    vals = np.array(vals)
+    assert abs(vals.mean() - 0.5) < 0.03 and abs(vals.var() - 1 / 12) < 0.01
 
 
 def test_rng_uniform_normal_moments():

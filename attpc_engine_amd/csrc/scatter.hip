@@ -132,10 +132,15 @@ constexpr int CTRL_MISMATCH = 31;    // out.ctrl[]: windows whose occupied-slot 
 // merge variant (scatter_kernel<false, true>): a wave works on MERGE_SEQ_PER_WAVE sequences of consecutive entries of
 // the window at a time, ten lanes (the mesh lines of constant y) per sequence; MERGE_G entries of every sequence are
 // staged per round
+#ifndef ATTPC_SC_MERGE_EXTRA  // LDS left beside the default kernel's arrays (one workgroup per CU: 160 KiB, two: 80 KiB each)
+#define ATTPC_SC_MERGE_EXTRA (ATTPC_SC_WG_PER_CU == 1 ? 5800 : 1040)
+#endif
 constexpr int MERGE_SEQ_PER_WAVE = 64 / MESH;
 constexpr int MERGE_NSEQ = N_WAVES * MERGE_SEQ_PER_WAVE;
-constexpr int MERGE_G = STAGE / MERGE_NSEQ;
-constexpr int MERGE_ROUND = MERGE_NSEQ * MERGE_G;  // entries staged per round
+constexpr int MERGE_ENTRY_BYTES = 8 + 2 * 2 * MESH + 4;  // electrons f64, 2 x 10 LUT indices i16, time bucket word
+constexpr int MERGE_STAGE_BYTES = STAGE * MERGE_ENTRY_BYTES + SORT_CAP * 2 + ATTPC_SC_MERGE_EXTRA;  // st_n .. merge_extra
+constexpr int MERGE_G = MERGE_STAGE_BYTES / MERGE_ENTRY_BYTES / MERGE_NSEQ;  // entries of a sequence staged per round
+constexpr int MERGE_ROUND = MERGE_NSEQ * MERGE_G;  // entries staged per round (MergeStage capacity)
 constexpr uint32_t MERGE_INVALID = 0xFFFFFFFFu;    // meta word of an entry outside 0 <= time bucket < 512
 static_assert(MERGE_G >= 1, "at least one staged entry per sequence and round");
 static_assert(STAGE <= SC_THREADS, "one lane per staged entry");
@@ -185,15 +190,18 @@ struct __align__(16) ScatterShared {
   short st_ix[STAGE][MESH];   // the lane's coordinate: LUT index of the y mesh line i, lut_n = off the pad plane
   short st_iy[STAGE][MESH];   // the stepped coordinate: LUT index of the x mesh line j
   int st_tb[STAGE];           // bits 0..9 time bucket, 24..26 position in `indices`, 30 point transport
+  unsigned short perm[SORT_CAP];    // entries (sample x slice) sorted by time bucket, events of <= SORT_CAP entries;
+                                    // longer events: lowest / highest time bucket of every chunk of SC_THREADS entries
+                                    // (two u32 per chunk: chunk_lo(), chunk_hi())
+  // The merge variant keeps its sorted entry list in global memory and has no use for perm[]: its staging arrays
+  // (MergeStage below) lie over st_n .. merge_extra as one block, with room for more entries per round than STAGE.
+  char merge_extra[ATTPC_SC_MERGE_EXTRA];
   int blocks[ATTPC_MAX_SIM][LDS_BLOCKS];  // the first arena block ids of the event's tracks (a sorted event has no others)
   long long label_of[ATTPC_MAX_SIM];  // row number (label) of each simulated nucleus
   int cnt[ATTPC_MAX_SIM + 1]; // exclusive prefix of kept samples per simulated nucleus
   unsigned long long cum[ATTPC_NUM_TB];  // inclusive prefix sums per time bucket: low word estimated keys,
                                          // high word staged entries (samples x slices)
   unsigned long long wave_sum[SC_THREADS / 64];
-  unsigned short perm[SORT_CAP];    // entries (sample x slice) sorted by time bucket, events of <= SORT_CAP entries;
-                                    // longer events: lowest / highest time bucket of every chunk of SC_THREADS entries
-                                    // (two u32 per chunk: chunk_lo(), chunk_hi())
   int stage_sum[2][SC_THREADS / 64];  // in-window entries per wave of a staging chunk (double buffered)
   int win_a, win_b, win_samples, win_r0, win_n, budget, overflow, done, ev_failed, failed, retried;
   unsigned int wg_cursor, n_keys, batch_first;
@@ -203,6 +211,30 @@ struct __align__(16) ScatterShared {
   unsigned long long ev_rows;                             // rows of the current event flushed so far (thread 0)
   unsigned long long charge_sum, key_sum;
 };
+
+static_assert(sizeof(ScatterShared) <= (ATTPC_SC_WG_PER_CU == 1 ? 163840 : 81920), "LDS of a CU / of half a CU");
+
+// The merge variant's staging arrays: the same four arrays as st_n / st_ix / st_iy / st_tb, MERGE_ROUND entries each,
+// laid over ScatterShared::st_n .. merge_extra.
+struct MergeStage {
+  double* n;
+  short (*ix)[MESH];
+  short (*iy)[MESH];
+  int* tb;
+};
+__device__ __forceinline__ MergeStage merge_stage(ScatterShared& sh) {
+  static_assert(offsetof(ScatterShared, merge_extra) + ATTPC_SC_MERGE_EXTRA - offsetof(ScatterShared, st_n) >= MERGE_ROUND * MERGE_ENTRY_BYTES &&
+                    offsetof(ScatterShared, st_ix) == offsetof(ScatterShared, st_n) + STAGE * 8 &&
+                    offsetof(ScatterShared, perm) == offsetof(ScatterShared, st_tb) + STAGE * 4 &&
+                    offsetof(ScatterShared, merge_extra) == offsetof(ScatterShared, perm) + SORT_CAP * 2,
+                "the merge staging block is contiguous and large enough");
+  MergeStage m;
+  m.n = &sh.st_n[0];
+  m.ix = reinterpret_cast<short (*)[MESH]>(m.n + MERGE_ROUND);
+  m.iy = m.ix + MERGE_ROUND;
+  m.tb = reinterpret_cast<int*>(m.iy + MERGE_ROUND);
+  return m;
+}
 
 // sample c of the event's concatenated tracks -> record pointer and position in `indices`.  `table` = the event's
 // rows of the block table in global memory: only events too long to be sorted (more than SORT_CAP entries) have
@@ -1105,6 +1137,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
         // handed to stream_insert() when it is nearly full, and drained at the window's last round (`last`).
         auto rows_round_merge = [&](MergeAcc& m, InsertCarry& carry, bool last) -> bool {
           const int wave = tid >> 6;
+          const MergeStage ms = merge_stage(sh);
           uint2* __restrict__ queue = sh.queue[wave];
           const char* __restrict__ lut_bytes = reinterpret_cast<const char*>(lut);
           const unsigned int row_pitch = 2u * (unsigned int)(lut_n + 1);
@@ -1158,13 +1191,13 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           };
           for (int qs = 0; qs < MERGE_G && ok; ++qs) {  // wave-uniform trip count
             const int st = slot0 + qs;
-            const int tbw = sh.st_tb[st];
+            const int tbw = ms.tb[st];
             const bool have = lane_ok && tbw >= 0;
             const bool point = (tbw & (1 << 30)) != 0;
             const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
-            const double n_el = sh.st_n[st];
-            const int ix = sh.st_ix[st][i];
-            const uint32_t* __restrict__ iy32 = reinterpret_cast<const uint32_t*>(&sh.st_iy[st][0]);
+            const double n_el = ms.n[st];
+            const int ix = ms.ix[st][i];
+            const uint32_t* __restrict__ iy32 = reinterpret_cast<const uint32_t*>(&ms.iy[st][0]);
             const double2* __restrict__ w2 = reinterpret_cast<const double2*>(&sh.wtab[i * MESH]);
             unsigned int iy[MESH];
             double w[MESH];
@@ -1284,20 +1317,42 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           const double xlo = xy.x - 3.0 * sigma, xhi = xy.x + 3.0 * sigma;
           const double ylo = xy.y - 3.0 * sigma, yhi = xy.y + 3.0 * sigma;
           const double sx = (xhi - xlo) / (double)(MESH - 1), sy = (yhi - ylo) / (double)(MESH - 1);
-          // (merge variant: staged inside the rows loop with the accumulators live -- rolled, so that the ten
-          //  lines' temporaries do not all need registers at once)
-#pragma unroll(MERGE ? 1 : MESH)
-          for (int i = 0; i < MESH; ++i) {
+          auto mesh_line = [&](int i) {
             const double x = (i == MESH - 1) ? xhi : (double)i * sx + xlo;
             const double y = (i == MESH - 1) ? yhi : (double)i * sy + ylo;
             const double fx = floor(x * 1000.0), fy = floor(y * 1000.0);
             // lanes are mesh lines of constant y that step through x: 8 % fewer runs than the other way
             // round on the AT-TPC pad plane (the weights are symmetric, so the pixels are the same)
-            sh.st_iy[slot][i] = (fx >= lo_mm && fx < hi_mm) ? (short)((int)fx - lut_lo) : (short)lut_n;
-            sh.st_ix[slot][i] = (fy >= lo_mm && fy < hi_mm) ? (short)((int)fy - lut_lo) : (short)lut_n;
+            const short vy = (fx >= lo_mm && fx < hi_mm) ? (short)((int)fx - lut_lo) : (short)lut_n;
+            const short vx = (fy >= lo_mm && fy < hi_mm) ? (short)((int)fy - lut_lo) : (short)lut_n;
+            if constexpr (MERGE) {
+              const MergeStage ms = merge_stage(sh);
+              ms.iy[slot][i] = vy;
+              ms.ix[slot][i] = vx;
+            } else {
+              sh.st_iy[slot][i] = vy;
+              sh.st_ix[slot][i] = vx;
+            }
+          };
+          if constexpr (MERGE) {
+            // staged inside the rows loop with the accumulators live: rolled, so that the ten lines' temporaries do
+            // not all need registers at once
+#pragma unroll 1
+            for (int i = 0; i < MESH; ++i) mesh_line(i);
+          } else {
+#pragma unroll
+            for (int i = 0; i < MESH; ++i) mesh_line(i);
           }
-          sh.st_n[slot] = (n_slices == 1 ? 1.0 : a.det.long_weights[sl]) * tn.y;  // x 1.0 is exact
-          sh.st_tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
+          const double n_staged = (n_slices == 1 ? 1.0 : a.det.long_weights[sl]) * tn.y;  // x 1.0 is exact
+          const int tb_staged = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
+          if constexpr (MERGE) {
+            const MergeStage ms = merge_stage(sh);
+            ms.n[slot] = n_staged;
+            ms.tb[slot] = tb_staged;
+          } else {
+            sh.st_n[slot] = n_staged;
+            sh.st_tb[slot] = tb_staged;
+          }
         };
         if constexpr (MERGE) {
           // The window is mg_perm[win_r0 .. win_r0 + win_n), cut into MERGE_NSEQ sequences of seq_len consecutive
@@ -1334,12 +1389,13 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
               } else {
                 // no entry: the lanes of this slot skip the step -- their gathers still run, so the slot's indices
                 // must point into the table ("off the pad plane"), not at whatever the LDS held
-                sh.st_tb[slot] = -1;
-                sh.st_n[slot] = 0.0;
+                const MergeStage ms = merge_stage(sh);
+                ms.tb[slot] = -1;
+                ms.n[slot] = 0.0;
 #pragma unroll
                 for (int k = 0; k < MESH; ++k) {
-                  sh.st_ix[slot][k] = (short)lut_n;
-                  sh.st_iy[slot][k] = (short)lut_n;
+                  ms.ix[slot][k] = (short)lut_n;
+                  ms.iy[slot][k] = (short)lut_n;
                 }
               }
             }

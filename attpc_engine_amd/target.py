@@ -77,6 +77,9 @@ def _elemental_stopping(zp: int, mp_mev: float, ke_mev: float, zt: int, at_u: fl
     return s_elec + s_nuc
 
 
+_ELOSS_MEMO: dict = {}  # GasTarget.get_energy_loss results of this process (a pure function of its arguments)
+
+
 class GasTarget:
     """API-compatible stand-in for ``spyral_utils.nuclear.target.GasTarget``.
 
@@ -93,6 +96,7 @@ class GasTarget:
     def __init__(self, compound, pressure: float, nuclear_map):
         self.compound = [(int(z), int(a), int(s)) for (z, a, s) in compound]
         self.pressure = float(pressure)
+        self.compound_key = tuple(self.compound)
         self._elements = []
         molar_mass = 0.0
         for z, a, s in self.compound:
@@ -118,6 +122,13 @@ class GasTarget:
     def get_energy_loss(self, projectile_data, projectile_energy: float, distances) -> np.ndarray:
         """Energy lost (MeV) after each path length in ``distances`` (m); RK4 in path length."""
         distances = np.atleast_1d(np.asarray(distances, dtype=float))
+        # a pure function of (gas, projectile, energy, distances), and a slow one in pure Python (one RK4 integration per
+        # distance: seconds for the 2049-node table a pipeline configures): remembered per process
+        memo_key = (self.compound_key, self.pressure, int(projectile_data.Z), float(projectile_data.mass),
+                    float(projectile_energy), distances.tobytes())
+        cached = _ELOSS_MEMO.get(memo_key)
+        if cached is not None:
+            return cached.copy()
         out = np.zeros_like(distances)
         scale = self.density * 100.0  # MeV/(g/cm^2) -> MeV/m
 
@@ -140,6 +151,9 @@ class GasTarget:
                     e = 0.0
                     break
             out[i] = projectile_energy - e
+        if len(_ELOSS_MEMO) >= 64:
+            _ELOSS_MEMO.clear()
+        _ELOSS_MEMO[memo_key] = out.copy()
         return out
 
     def get_number_density(self) -> float:

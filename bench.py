@@ -62,9 +62,12 @@ def parse_args(argv=None) -> argparse.Namespace:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-delivered", action="store_true", help="skip the delivered-to-host leg (clouds over PCIe)")
     ap.add_argument("--delivered-events", type=int, default=60_000)
-    ap.add_argument("--no-hint", action="store_true",
-                    help="do not announce the next step to the engine (attpc_sim_hint_next): every step then starts with "
-                         "its first track batch standing alone (A/B of the hint)")
+    ap.add_argument("--hint", action="store_true",
+                    help="announce the next step to the engine (attpc_sim_hint_next): its first track batch is then integrated "
+                         "behind this step's last scatter launches instead of standing alone at its head.  Off by default: "
+                         "measured slower (197.4 against 192.7 ms per 1e6-event step, profiles/r03_hint_ab.md) -- both "
+                         "kernels are issue bound, and the scatter launches lose more beside the track kernel than the "
+                         "8 ms the track batch takes alone")
     ap.add_argument("--stub-engine", action="store_true",
                     help="TEST ONLY: no GPU, no library -- a stand-in engine with made-up statistics, so that the "
                          "launcher / sharding / reduction path runs on a CPU box; the line says data = 'stub'")
@@ -193,7 +196,7 @@ def main(argv=None) -> int:
     my_events = 0
     for step in range(args.steps):
         first, n = step_range(step)
-        if step + 1 < args.steps and hasattr(engine, "hint_next") and not args.no_hint:
+        if step + 1 < args.steps and hasattr(engine, "hint_next") and args.hint:
             # a stream of calls: say what the next one will be, so that its first track batch is integrated behind
             # this call's last scatter launches.  Never across the edges of the timed region: the last warm-up step
             # announces nothing (step 0 does all of its own work in here), and the last timed step neither.

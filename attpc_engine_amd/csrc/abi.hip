@@ -103,7 +103,7 @@ struct attpc_ctx {
   bool opt_tiny = false;
   int opt_compact = 2;             // delivered clouds cross PCIe as 8-byte (2) / 16-byte (1) records and are expanded
                                    // by host threads, or in the reference's dtypes (0)
-  int opt_unpack_threads = 0;      // 0: min(16, hardware threads)
+  int opt_unpack_threads = 0;      // 0: min(32, half of the hardware threads)
   int opt_deliver_chunk = 8192;    // events per chunk when clouds are delivered (the pipeline's fill and drain time)
   int opt_merge = -1;              // scatter kernel's merge variant: -1 automatic (path-length dE/dx step), 0 never, 1 always
 

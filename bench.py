@@ -44,7 +44,7 @@ N_CUS, SIMDS_PER_CU, N_XCDS = 256, 4, 8
 # LDS atomics: an LDS instruction of a wave64 is serviced 32 lanes per LDS cycle at best (two lane groups,
 # MI355X_MICROARCH.md "LDS"), one LDS pipeline per CU -> at most CLOCK / 2 wave-level atomics per CU and second
 LDS_ATOMIC_PEAK_PER_S = N_CUS * CLOCK_HZ / 2.0
-PMC_PROFILE = "r02_pmc.json"
+PMC_PROFILE = "r03_pmc.json"
 
 
 def parse_args(argv=None) -> argparse.Namespace:
@@ -126,7 +126,7 @@ class StubEngine:
         return {"stats": {"ms_kinematics": 0.0, "ms_tracks": 0.1, "ms_scatter": 1.0, "launches_kinematics": 0,
                           "launches_tracks": 1, "launches_scatter": 1, "n_points": points, "n_track_samples": 10 * n_events,
                           "n_failed": 0, "n_sample_limit": 0, "n_lone_buckets": 0, "n_inconsistent": 0,
-                          "n_buffer_growths": 0, "charge_checksum": (sum(ids) * 0x9E3779B97F4A7C15) % (1 << 64),
+                          "n_buffer_growths": 0, "n_tracks_capped": 0, "charge_checksum": (sum(ids) * 0x9E3779B97F4A7C15) % (1 << 64),
                           "key_checksum": (sum(ids) * (2 * seed + 1)) % (1 << 64)}}
 
 
@@ -191,7 +191,7 @@ def main(argv=None) -> int:
     agg = {"ms_kinematics": 0.0, "ms_tracks": 0.0, "ms_scatter": 0.0, "launches_kinematics": 0,
            "launches_tracks": 0, "launches_scatter": 0}
     totals = {"n_points": 0, "n_track_samples": 0, "n_failed": 0, "n_sample_limit": 0, "n_lone_buckets": 0,
-              "n_inconsistent": 0, "n_buffer_growths": 0}
+              "n_inconsistent": 0, "n_buffer_growths": 0, "n_tracks_capped": 0}
     charge_acc = key_acc = 0
     my_events = 0
     for step in range(args.steps):
@@ -271,6 +271,9 @@ def main(argv=None) -> int:
             "buffer_growths_in_timed_steps": totals["n_buffer_growths"],
             "table_self_check_failures": totals["n_inconsistent"],
             "sample_limit_events": limit,
+            # path-length dE/dx step only: tracks cut at the 10 001-sample cap before the end of the 1 us window
+            # (rank 0's share; always 0 on the reference's time grid)
+            "tracks_cut_at_the_sample_cap": totals["n_tracks_capped"],
             "charge_checksum": str(charge_sum),  # u64 sums over all steps and ranks, as strings (beyond int64 / f64)
             "key_checksum": str(key_sum),
         },
@@ -290,7 +293,8 @@ def main(argv=None) -> int:
             "per": "GPU (rank 0's launches)",
             # kin_run_kernel is left out: its HIP events sit on the low-priority stream and measure the wait for
             # compute units behind the scatter workgroups, not the ~50 us the kernel runs (profiles/ kernel stats)
-            "kernel_ms_total": {k: agg[v[0]] for k, v in kernels.items()},
+            "kernel_ms_total": {"scatter_kernel": agg["ms_scatter"],
+                                "track_kernel_incl_wait_on_the_low_priority_stream": agg["ms_tracks"]},
             "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md 4.3): frac is vs the HBM roof as the "
                     "contract asks, valu_issue_frac is the roof that binds",
             **issue,
@@ -369,7 +373,7 @@ def delivered(engine, n: int, seed: int, bytes_per_event: float, p_event: float)
     dtypes, CSR) and, second, with the GET response / ADC threshold / Spyral rows / z-sort done on the device and
     only those rows delivered.  One untimed pass sizes the buffers and touches their pages."""
     out = {"events": n,
-           "host_buffers": "ordinary numpy arrays, reused across calls (rows cross PCIe as 16-byte / 24-byte transfer records "
+           "host_buffers": "ordinary numpy arrays, reused across calls (rows cross PCIe as 8-byte / 24-byte transfer records "
                            "into library-owned pinned staging; host threads expand them to the reference's dtypes)"}
     cap = int(p_event * 1.25) + 64
     for name, run in (("cloud", lambda first: engine.run(n, seed=seed, first_event=first, fetch=True, pinned=False,
@@ -392,7 +396,7 @@ def delivered(engine, n: int, seed: int, bytes_per_event: float, p_event: float)
             engine._out_cache = None
         width = 3 if name == "cloud" else 8
         delivered_bytes = rows * (width + 1) * 8 + (n + 1) * 8
-        link_bytes = rows * (16 if name == "cloud" else 24) + (n + 1) * 8
+        link_bytes = rows * (8 if name == "cloud" else 24) + (n + 1) * 8  # 8-byte / 24-byte transfer records
         out[name] = {"events_per_s": n / dt, "rows_per_event": rows / n, "bytes_per_event": delivered_bytes / n,
                      "pcie_bytes_per_event": link_bytes / n, "pcie_GBps": link_bytes / dt / 1e9}
     return out

@@ -12,8 +12,10 @@ pipe, cfg, idx = workloads.o16aa()
 ctx = _abi.Context(0)
 eng = Engine(pipe, cfg, idx, context=ctx)
 eng.run(1000000, seed=3)
-for chunk in (16384, 8192, 4096, 2048):
+for chunk, threads, compact in ((8192, 0, 2), (16384, 0, 2), (32768, 0, 2), (8192, 32, 2), (16384, 32, 2), (8192, 0, 1), (4096, 0, 2)):
     ctx.set_option("deliver_chunk_events", chunk)
+    ctx.set_option("unpack_threads", threads)
+    ctx.set_option("compact_transfer", compact)
     for name in ("cloud", "spyral"):
         best = 0.0
         for rep in range(3):
@@ -27,4 +29,4 @@ for chunk in (16384, 8192, 4096, 2048):
                 best = max(best, n / dt)
         eng._out_cache = None
         del res
-        print("chunk", chunk, name, round(best), "events/s", flush=True)
+        print("chunk", chunk, "unpack_threads", threads, "compact_transfer", compact, name, round(best), "events/s", flush=True)

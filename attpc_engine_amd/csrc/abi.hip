@@ -39,7 +39,7 @@ namespace {
 using namespace attpc;
 
 constexpr int MAX_SLOTS = 8;           // scatter chunks per track batch
-constexpr int CTRL_WORDS = 32;         // u64 control words per scatter launch (scatter.hip)
+constexpr int CTRL_WORDS = 40;         // u64 control words per scatter launch (scatter.hip: 0..32 used)
 constexpr uint32_t LONE_CAPACITY = 65536;
 constexpr int64_t CLOUD_BUDGET_BYTES = 24ll << 30;  // points + labels of one chunk
 constexpr int64_t DELIVER_CHUNK_ROWS = 96ll << 20;  // cloud rows of a chunk whose cloud is delivered (3 GB: ~60 ms of PCIe)
@@ -99,7 +99,7 @@ struct attpc_ctx {
   hipStream_t stream_c = nullptr;  // C
   std::string error;
   int32_t chunk_events = 65536;
-  int opt_variant = 0;             // 0 auto, 1 small, 2 big
+  int opt_variant = 0;             // 0 auto, 1 small, 2 big, 3 wide (u64 sums)
   bool opt_tiny = false;
   int opt_compact = 2;             // delivered clouds cross PCIe as 8-byte (2) / 16-byte (1) records and are expanded
                                    // by host threads, or in the reference's dtypes (0)
@@ -128,6 +128,8 @@ struct attpc_ctx {
   double segs_per_event = 0.0;
   double blocks_per_track = 0.0;   // observed arena blocks per track
   bool prefer_big = false;         // sticky: the small scatter variant met too many lone buckets
+  bool prefer_wide = false;        // sticky: u32 sums per table slot are not enough for this detector (scatter_wide.hip)
+  bool slot_wide[8] = {};          // per control-word slot: the launch queued last used the wide build
   bool lone_ready = false;         // lone_bucket_kernel's tables are allocated AND their zeroing has been queued
   uint64_t n_growths = 0;          // device buffers (re)allocated so far (a steady workload stops growing)
   uint64_t device_bytes = 0;       // bytes of the grow-only device buffers (ensure()) held right now
@@ -253,7 +255,7 @@ int32_t validate_layout(attpc_ctx* ctx, const attpc_event_layout* lay, bool with
 
 struct ChunkResult {
   unsigned long long rows = 0, reserved = 0, segs = 0, charge = 0, keys = 0, failed = 0, retried = 0, samples = 0,
-                     mismatch = 0, lone = 0;
+                     mismatch = 0, lone = 0, danger = 0;
   bool overflow = false;
   float ms_scatter = 0;
 };
@@ -508,6 +510,7 @@ uint32_t next_chunk_events(const attpc_ctx* ctx, uint64_t remaining) {
 // ------------------------------------------------------------------ scatter ----
 struct ScatterPlan {  // launch geometry of one chunk
   bool use_small = false;
+  bool use_wide = false;  // u64 sums per table slot (scatter_wide.hip), one workgroup per CU like the big build
   uint32_t wgs = 0, batch = 1, row_block = 1;
   int64_t need_rows = 0, need_segs = 0;  // the launch should fit in this much
   int64_t grow_rows = 0, grow_segs = 0;  // what to allocate when the buffers are smaller than that
@@ -526,6 +529,10 @@ ScatterPlan plan_scatter(const attpc_ctx* ctx, uint32_t n) {
   p.use_small = far_keys <= 40.0 && !ctx->det.mc_diffusion && !(ctx->det.longitudinal_diffusion > 0.0) && !ctx->prefer_big;
   if (ctx->opt_variant == 1) p.use_small = true;
   if (ctx->opt_variant == 2) p.use_small = false;
+  // u32 sums per slot hold what the AT-TPC makes (largest key of the headline workload: 1.1e9 electrons); a launch in
+  // which many windows had to be given to lone_bucket_kernel (read_scatter) switches the context to the u64 build
+  p.use_wide = ctx->opt_variant == 3 || (ctx->prefer_wide && ctx->opt_variant == 0);
+  if (p.use_wide) p.use_small = false;
 #ifndef ATTPC_SC_SMALL_WGS
 #define ATTPC_SC_SMALL_WGS 2  // workgroups per CU of the small variant (scatter_small.hip)
 #endif
@@ -614,7 +621,9 @@ int32_t enqueue_scatter(attpc_ctx* ctx, int slot, const attpc_event_layout& lay,
   sa.merge_scratch = merge ? static_cast<uint2*>(ctx->merge_scratch.p) : nullptr;
   sa.merge_cap = (uint32_t)merge_cap;
   HIP_TRY(ctx, hipEventRecord(ctx->s0[slot], ctx->stream));
-  if (p.use_small) launch_scatter_kernel_small(p.wgs, ctx->stream, sa);
+  ctx->slot_wide[slot] = p.use_wide;
+  if (p.use_wide) launch_scatter_kernel_wide(p.wgs, ctx->stream, sa);
+  else if (p.use_small) launch_scatter_kernel_small(p.wgs, ctx->stream, sa);
   else launch_scatter_kernel_big(p.wgs, ctx->stream, sa);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->s1[slot], ctx->stream));
@@ -645,6 +654,18 @@ void read_scatter(attpc_ctx* ctx, int slot, uint32_t n, ChunkResult* r, int64_t*
   r->overflow = o[6] != 0;
   r->reserved = o[0];
   r->segs = o[1];
+  r->danger = o[32];
+  // Windows whose u32 sums could have wrapped were done again by lone_bucket_kernel, one time bucket at a time: exact,
+  // but meant for the odd window.  Where they are many (more than one per 64 events), or the list of lone buckets ran
+  // over because of them, this detector needs u64 sums: the context switches to the wide build for good and this
+  // launch is repeated with it (results do not depend on the build).
+  if (!ctx->slot_wide[slot] && ctx->opt_variant == 0 && r->danger && (r->danger * 64ull > (unsigned long long)n || o[4] != 0)) {
+    ctx->prefer_wide = true;
+    r->overflow = true;
+    *min_rows = std::max<int64_t>(*min_rows, ctx->launch_row_cap);
+    *min_segs = std::max<int64_t>(*min_segs, ctx->seg_capacity);
+    return;
+  }
   if (r->overflow) {  // cloud / segment capacity exceeded (the cursors kept counting)
     *min_rows = (int64_t)(o[0] + o[0] / 8) + 65536;
     *min_segs = (int64_t)(o[1] + o[1] / 8) + 4096;
@@ -1281,7 +1302,7 @@ int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value) {
   if (!ctx || !name) return ATTPC_E_INVALID;
   const std::string key(name);
   if (key == "scatter_variant") {
-    if (value < 0 || value > 2) return fail(ctx, ATTPC_E_INVALID, "scatter_variant must be 0, 1 or 2");
+    if (value < 0 || value > 3) return fail(ctx, ATTPC_E_INVALID, "scatter_variant must be 0, 1, 2 or 3");
     ctx->opt_variant = (int)value;
   } else if (key == "tiny_buffers") {
     ctx->opt_tiny = value != 0;
@@ -1522,6 +1543,7 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
   ctx->det_ready = false;
   ctx->rows_per_event = ctx->segs_per_event = ctx->blocks_per_track = 0.0;  // size estimates start over
   ctx->prefer_big = false;
+  ctx->prefer_wide = false;
   DetDev dv{};
   dv.length = d->length; dv.efield = d->efield; dv.bfield = d->bfield; dv.density = d->density;
   dv.diffusion = d->diffusion; dv.fano_factor = d->fano_factor; dv.w_value = d->w_value;

@@ -108,7 +108,23 @@ constexpr int MAX_CHUNKS = SORT_CAP / 4;         // chunks of an unsorted event 
                                                  // one stands for all further chunks)
 constexpr int SORT_PER_THREAD = (SORT_CAP + SC_THREADS - 1) / SC_THREADS;
 constexpr int HASH_BITS = ATTPC_SC_HASH_BITS;
-constexpr int HASH_CAP = 1 << HASH_BITS;         // slots
+// Slots of the table.  Default: 8 bytes each (u32 key | label word + u32 electrons), 1.5 x 2^HASH_BITS of them in the
+// 12 bytes x 2^HASH_BITS the first table took (u64 electrons) -- a third fewer windows per event, each with its
+// selection, barriers, compaction and partial passes (-6.6 % kernel time on the headline workload).  A key's electrons
+// fit u32 in practice (largest sum met in 2.2e7 points of the headline workload: 1.1e9); a window in which one may not
+// is done again by lone_bucket_kernel (u64 sums), see ADD_LIMIT -- and a detector where that is the rule (a gain far
+// beyond the AT-TPC's) runs the third build of this file, scatter_wide.hip (ATTPC_SC_WIDE_CHARGE: u64 electrons per
+// slot, the first table), which the host switches to by itself (abi.hip, prefer_wide).
+#ifndef ATTPC_SC_WIDE_CHARGE
+#define ATTPC_SC_WIDE_CHARGE 0
+#endif
+#if ATTPC_SC_WIDE_CHARGE
+using charge_t = unsigned long long;
+constexpr int HASH_CAP = 1 << HASH_BITS;         // slots (8 192)
+#else
+using charge_t = uint32_t;
+constexpr int HASH_CAP = 3 << (HASH_BITS - 1);   // slots (6 144 / 12 288)
+#endif
 constexpr int TARGET_KEYS = HASH_CAP * ATTPC_SC_TARGET_PCT / 100;  // aimed-at fill: inserts slow down steeply beyond ~55 %
 #ifndef ATTPC_SC_BUDGET_MAX_MULT
 #define ATTPC_SC_BUDGET_MAX_MULT 64
@@ -129,6 +145,7 @@ constexpr int CTRL_NEXT_EVENT = 28;  // out.ctrl[]: next unassigned event of the
 constexpr int CTRL_LONE = 29;        // out.ctrl[]: time buckets left to lone_bucket_kernel (entries of out.lone_list)
 constexpr int CTRL_ROWS = 30;        // out.ctrl[]: rows actually written ([0] is the reservation cursor)
 constexpr int CTRL_MISMATCH = 31;    // out.ctrl[]: windows whose occupied-slot count differed from the claimed keys
+constexpr int CTRL_DANGER = 32;      // out.ctrl[]: windows given to lone_bucket_kernel because a u32 sum could have wrapped
 // merge variant (scatter_kernel<false, true>): a wave works on MERGE_SEQ_PER_WAVE sequences of consecutive entries of
 // the window at a time, ten lanes (the mesh lines of constant y) per sequence; MERGE_G entries of every sequence are
 // staged per round
@@ -144,7 +161,7 @@ constexpr int MERGE_ROUND = MERGE_NSEQ * MERGE_G;  // entries staged per round (
 constexpr uint32_t MERGE_INVALID = 0xFFFFFFFFu;    // meta word of an entry outside 0 <= time bucket < 512
 static_assert(MERGE_G >= 1, "at least one staged entry per sequence and round");
 static_assert(STAGE <= SC_THREADS, "one lane per staged entry");
-static_assert(2 * N_WAVES * (WAVE_QUEUE + 2) >= HASH_CAP, "the wave queues double as the slot list of a flush");
+static_assert(4 * N_WAVES * (WAVE_QUEUE + 2) >= HASH_CAP && HASH_CAP <= 65536, "the wave queues double as the (16-bit) slot list of a flush");
 static_assert(2 * MAX_CHUNKS * sizeof(uint32_t) <= SORT_CAP * sizeof(unsigned short), "chunk ranges overlay perm[]");
 
 // Drift time of slice `sl` of a sample created at time bucket t: the sample itself without the
@@ -182,8 +199,8 @@ static_assert(2 * sizeof(short) * STAGE * MESH >= sizeof(uint32_t) * ATTPC_NUM_T
 struct __align__(16) ScatterShared {
   double wtab[PIXELS];        // first member: rows of 10 weights are read as five 16-byte pairs
   uint32_t keys[HASH_CAP];    // bits 0..13 pad, 14..23 time bucket, 24..26 position in `indices`
-  unsigned long long chg[HASH_CAP];  // electrons per key (ds_add_u64); keys and chg sit below 64 KiB in both builds:
-                                     // stream_insert() addresses them through the 16-bit offset field
+  charge_t chg[HASH_CAP];     // electrons per key (ds_add_rtn_u32 / ds_add_u64); keys and chg sit below 64 KiB in
+                              // every build: stream_insert() addresses them through the 16-bit offset field
   uint2 queue[N_WAVES][WAVE_QUEUE + 2];  // per wave: (key|label, charge) of queued runs (+ dump slot);
                                          // the whole array is the slot list during a flush
   double st_n[STAGE];         // electrons x gain (x the slice weight of the longitudinal extension)
@@ -204,6 +221,7 @@ struct __align__(16) ScatterShared {
   unsigned long long wave_sum[SC_THREADS / 64];
   int stage_sum[2][SC_THREADS / 64];  // in-window entries per wave of a staging chunk (double buffered)
   int win_a, win_b, win_samples, win_r0, win_n, budget, overflow, done, ev_failed, failed, retried;
+  int danger;  // an add of this window met a sum >= 2^31 (ADD_LIMIT): its time buckets go to lone_bucket_kernel
   unsigned int wg_cursor, n_keys, batch_first;
   unsigned long long base;
   unsigned long long row_cur, row_end, seg_cur, seg_end;  // this workgroup's reserved output rows / segment slots
@@ -258,7 +276,7 @@ __device__ __forceinline__ const double* sample_ptr(const ScatterShared& sh, con
 __device__ __forceinline__ void clear_table(ScatterShared& sh) {
   for (int i = threadIdx.x; i < HASH_CAP; i += SC_THREADS) {
     sh.keys[i] = EMPTY;
-    sh.chg[i] = 0ull;
+    sh.chg[i] = (charge_t)0;
   }
 }
 
@@ -267,6 +285,7 @@ __device__ __forceinline__ void clear_table(ScatterShared& sh) {
 // search step over every 8th entry and an 8-way step inside the block found -- two LDS round trips
 // instead of the nine of a binary search (the selection sits on the workgroup's critical path).
 static_assert(ATTPC_NUM_TB == 64 * 8, "wave_upper_bound covers 8 buckets per lane");
+static_assert(HASH_CAP % (SC_THREADS) == 0, "the flush compacts HASH_CAP / N_WAVES slots per wave, 64 at a time");
 template <bool HIGH>
 __device__ __forceinline__ int wave_upper_bound(const unsigned long long* cum, int lo, int hi, unsigned int value,
                                                 int ln) {
@@ -288,8 +307,15 @@ constexpr int N_BUCKETS = HASH_CAP / BUCKET;
 constexpr int MAX_BUCKET_PROBES = 48;
 
 __device__ __forceinline__ uint32_t hash_bucket(uint32_t key) {
-  return (key * 2654435761u) >> (32 - (HASH_BITS - 2));
+  return __umulhi(key * 2654435761u, (uint32_t)N_BUCKETS);  // multiplicative hash, scaled to the (not 2^n) bucket count
 }
+__device__ __forceinline__ uint32_t next_bucket(uint32_t b) { return b + 1u == (uint32_t)N_BUCKETS ? 0u : b + 1u; }
+
+// Charges are u32 sums.  One add is below 2^31 (a run is at most ten pixels below 2^27 each, table_add() refuses more), so
+// a sum can only wrap if it was >= 2^31 before the add: every add RETURNS the old value, and bit 31 of any returned value
+// marks the window as dangerous.  A dangerous window is thrown away and its time buckets go to lone_bucket_kernel (u64
+// sums in global memory): exact, slow, and not met in the workloads of BASELINE.json.
+constexpr uint32_t ADD_LIMIT = 1u << 30;
 
 // points[key] = (charge + q, label) of transporter.py:247-249: find or claim the key's slot,
 // raise the label, add the charge.  `want` = key | label bits.  The table is bucketed: one
@@ -297,6 +323,12 @@ __device__ __forceinline__ uint32_t hash_bucket(uint32_t key) {
 // short at 50 % load (linear probing over single slots needed ~15 dependent round trips for
 // the slowest of 64 lanes).  False if the table is too full.
 __device__ __forceinline__ bool table_add(ScatterShared& sh, uint32_t want, unsigned long long q) {
+#if !ATTPC_SC_WIDE_CHARGE
+  if (q >= (unsigned long long)ADD_LIMIT) {  // no u32 add for this one: the window goes to lone_bucket_kernel
+    sh.danger = 1;
+    return true;
+  }
+#endif
   const uint32_t key = want & KEY_MASK;
   uint32_t b = hash_bucket(key);
   uint32_t h = 0, cur = 0;
@@ -324,10 +356,14 @@ __device__ __forceinline__ bool table_add(ScatterShared& sh, uint32_t want, unsi
       continue;  // lost the slot to another key: look at the bucket again
     }
     if (++probes >= MAX_BUCKET_PROBES) return false;
-    b = (b + 1) & (N_BUCKETS - 1);
+    b = next_bucket(b);
   }
   if (cur < want) atomicMax(&sh.keys[h], want);
+#if ATTPC_SC_WIDE_CHARGE
   atomicAdd(&sh.chg[h], q);
+#else
+  if (atomicAdd(&sh.chg[h], (uint32_t)q) >> 31) sh.danger = 1;
+#endif
   return true;
 }
 
@@ -361,14 +397,18 @@ __device__ __forceinline__ bool wave_insert(ScatterShared& sh, uint32_t want, ui
     const bool done = pending && (any_m || won || same);
     if (done) {
       if (cur < want) atomicMax(&sh.keys[h], want);
+#if ATTPC_SC_WIDE_CHARGE
       atomicAdd(&sh.chg[h], (unsigned long long)q);
+#else
+      if (atomicAdd(&sh.chg[h], q) >> 31) sh.danger = 1;
+#endif
     }
     claimed += (unsigned int)__popcll(__ballot(won));
     const bool advance = pending && !any_m && !any_e;  // full bucket of other keys
     probes += advance ? 1 : 0;
     const bool give_up = advance && probes >= MAX_BUCKET_PROBES;
     fail = fail || give_up;
-    b = advance ? ((b + 1) & (N_BUCKETS - 1)) : b;
+    b = advance ? next_bucket(b) : b;
     pending = pending && !done && !give_up;  // a lost compare-and-swap looks at the same bucket again
   }
   return !__any(fail);
@@ -385,8 +425,9 @@ __device__ __forceinline__ bool wave_insert(ScatterShared& sh, uint32_t want, ui
 struct InsertCarry {  // per lane
   uint32_t want, q;
   uint32_t b;         // bits 0..15 bucket, 16.. probes so far
+  uint32_t danger;    // OR of the old sums the adds returned (bit 31: see ADD_LIMIT)
   bool have;
-  __device__ __forceinline__ void reset() { want = 0u; q = 0u; b = 0u; have = false; }
+  __device__ __forceinline__ void reset() { want = 0u; q = 0u; b = 0u; danger = 0u; have = false; }
 };
 
 __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __restrict__ queue, int n_q, bool drain,
@@ -428,14 +469,18 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
     const bool done = c.have && (any_m || won || same);
     if (done) {
       if (cur < c.want) atomicMax(&sh.keys[h], c.want);
+#if ATTPC_SC_WIDE_CHARGE
       atomicAdd(&sh.chg[h], (unsigned long long)c.q);
+#else
+      c.danger |= atomicAdd(&sh.chg[h], c.q);
+#endif
     }
     claimed += (unsigned int)__popcll(__ballot(won));
     const bool advance = c.have && !any_m && !any_e;  // full bucket of other keys
     const uint32_t probes = (c.b >> 16) + (advance ? 1u : 0u);
     const bool give_up = advance && probes >= (uint32_t)MAX_BUCKET_PROBES;
     fail = fail || give_up;
-    c.b = (advance ? ((b + 1u) & (uint32_t)(N_BUCKETS - 1)) : b) | (probes << 16);
+    c.b = (advance ? next_bucket(b) : b) | (probes << 16);
     c.have = c.have && !done && !give_up;  // a lost compare-and-swap looks at the same bucket again
   }
   return !__any(fail);
@@ -452,8 +497,9 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
 // and the {q, 0} pair of the 64-bit add need consecutive, even-aligned registers); the operands bind them.
 struct InsertCarry {
   uint32_t want, q, ba;     // per lane: key | label, charge, byte offset of the bucket inside keys[]
+  uint32_t danger;          // per lane: OR of the old sums the adds returned (bit 31: see ADD_LIMIT)
   unsigned long long have;  // wave uniform: lanes with a run under way
-  __device__ __forceinline__ void reset() { want = 0u; q = 0u; ba = 0u; have = 0ull; }
+  __device__ __forceinline__ void reset() { want = 0u; q = 0u; ba = 0u; danger = 0u; have = 0ull; }
 };
 static_assert(offsetof(ScatterShared, keys) < 65536 && offsetof(ScatterShared, chg) < 65536,
               "keys[] / chg[] are addressed as register + 16-bit offset field");
@@ -469,10 +515,15 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
   claimed = (uint32_t)__builtin_amdgcn_readfirstlane(claimed);
   asm volatile(
       "s_mov_b32 s92, 0\n"              // next: first queue item nobody has taken yet
+#if ATTPC_SC_WIDE_CHARGE
       "v_mov_b32 v115, 0\n"             // v[114:115] = {q, 0}
+#else
+      "v_mov_b32 v124, 0\n"             // the old sum the lane's last add returned
+#endif
       "v_mov_b32 v126, -1\n"            // EMPTY
       "s_mov_b32 s99, 0\n"              // fail
       "v_mov_b32 v127, 0x9e3779b1\n"    // hash_bucket()'s multiplier
+      "s_mov_b32 s96, %[nb]\n"          // ... and its scale, the number of buckets
       "s_mov_b64 s[70:71], exec\n"       // every lane of the wave (the callers are wave uniform)
       "s_lshr_b32 s94, s93, 4\n"
       "s_add_i32 s94, s94, 64\n"        // trip budget of this call
@@ -497,8 +548,8 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
       "s_waitcnt lgkmcnt(1)\n"
       "v_and_b32 v121, 0xffffff, v112\n"
       "v_mul_lo_u32 v113, v121, v127\n"
-      "v_lshrrev_b32 v113, %[shift], v113\n"
-      "v_and_b32 v113, %[bmask], v113\n"        // bucket * 16
+      "v_mul_hi_u32 v113, v113, s96\n"          // bucket = (hash * buckets) >> 32
+      "v_lshlrev_b32 v113, 4, v113\n"           // * 16 bytes
       "s_mov_b64 exec, s[70:71]\n"
       "2:\n"
       "s_cmp_eq_u64 s[68:69], 0\n"
@@ -550,12 +601,18 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
       "ds_max_u32 v122, v112 offset:%[keys]\n"       // (a no-op where it is not lower; cheaper than finding out)
       "s_or_b64 s[90:91], exec, s[86:87]\n"          // done: the run's slot is known
       "s_mov_b64 exec, s[90:91]\n"
+#if ATTPC_SC_WIDE_CHARGE
       "v_lshlrev_b32 v120, 1, v122\n"
       "ds_add_u64 v120, v[114:115] offset:%[chg]\n"
+#else
+      "v_or_b32 %[danger], %[danger], v124\n"       // (what these lanes' previous add returned: long since arrived)
+      "ds_add_rtn_u32 v124, v122, v114 offset:%[chg]\n"  // the slot's u32 sum; the old value comes back (ADD_LIMIT)
+#endif
       "s_or_b64 s[76:77], s[82:83], s[84:85]\n"
       "s_andn2_b64 exec, s[68:69], s[76:77]\n"       // full bucket of other keys: on to the next one
       "v_add_u32 v113, 16, v113\n"
-      "v_and_b32 v113, %[bmask], v113\n"
+      "v_cmp_le_u32 vcc, %[nb16], v113\n"
+      "v_cndmask_b32 v113, v113, 0, vcc\n"          // ... around the end of the table
       "s_mov_b64 exec, s[70:71]\n"
       "s_andn2_b64 s[68:69], s[68:69], s[90:91]\n"   // a lost claim looks at the same bucket again
       "s_branch 1b\n"
@@ -569,13 +626,17 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
       "s_waitcnt lgkmcnt(0)\n"                       // (the budget exit can come straight after a fresh run's loads: the
                                                      //  compiler does not track LDS reads issued in here)
       "s_mov_b64 exec, s[70:71]\n"
-      : "+{v112}"(c.want), "+{v113}"(c.ba), "+{v114}"(c.q), "+{s[68:69]}"(c.have), "+{s95}"(claimed), "={s99}"(fail), "={s94}"(budget_left)
+#if !ATTPC_SC_WIDE_CHARGE
+      "v_or_b32 %[danger], %[danger], v124\n"       // what the last adds returned
+#endif
+      : "+{v112}"(c.want), "+{v113}"(c.ba), "+{v114}"(c.q), "+{s[68:69]}"(c.have), "+{s95}"(claimed), "={s99}"(fail), "={s94}"(budget_left),
+        [danger] "+v"(c.danger)
       : "{v111}"(qbase), "{s93}"(__builtin_amdgcn_readfirstlane(n_q)), "{s98}"((uint32_t)(drain ? 1u : 0u)),
-        [shift] "n"(32 - (HASH_BITS - 2) - 4), [bmask] "n"((N_BUCKETS - 1) * 16),
+        [nb] "n"(N_BUCKETS), [nb16] "n"(N_BUCKETS * 16),
         [keys] "n"(offsetof(ScatterShared, keys)), [chg] "n"(offsetof(ScatterShared, chg))
-      : "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v125", "v126", "v127", "s70", "s71",
+      : "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "s70", "s71",
         "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87",
-        "s88", "s89", "s90", "s91", "s92", "s97", "vcc", "scc", "memory");
+        "s88", "s89", "s90", "s91", "s92", "s96", "s97", "vcc", "scc", "memory");
   trips += ((uint32_t)n_q >> 4) + 64u - (fail ? 0u : budget_left);  // diagnostic builds only (dead code otherwise)
   return fail == 0u;
 }
@@ -761,7 +822,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
         }
         for (int k = n_sim; k <= ATTPC_MAX_SIM; ++k) sh.cnt[k] = acc;
         const int zero = local_const(0);
-        sh.win_a = zero; sh.win_b = zero; sh.budget = local_const(TK); sh.overflow = zero; sh.done = zero;
+        sh.win_a = zero; sh.win_b = zero; sh.budget = local_const(TK); sh.overflow = zero; sh.done = zero; sh.danger = zero;
         sh.ev_failed = zero;
         sh.ev_rows = 0ull;
         sh.wg_samples += (unsigned long long)acc;
@@ -1125,6 +1186,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             if (!ok) break;    // table too full: the whole wave stops together
           }
           if (ok && drain) ok = stream_insert(sh, queue, 0, true, carry, claimed, diag_trips);  // the runs still under way
+          if (carry.danger >> 31) sh.danger = 1;  // (never, for the workloads of BASELINE.json: ADD_LIMIT)
           if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);  // rows of the window's flush
           PHASE_COUNT(5, (unsigned long long)diag_trips + ((unsigned long long)diag_calls << 32));
           return ok;
@@ -1292,6 +1354,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             PHASE_MARK(11);
 #endif
           }
+          if (carry.danger >> 31) sh.danger = 1;
           if (lane == 0 && claimed) atomicAdd(&sh.n_keys, claimed);  // rows of the window's flush
           PHASE_COUNT(5, (unsigned long long)diag_trips);
           return ok;
@@ -1519,6 +1582,43 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           filled = filled_new;
         }
 
+        if (sh.danger) {  // (uniform: every thread sees the flag after the barrier that ended the rows phase)
+          // A sum of this window reached 2^31: a later add could have wrapped its u32.  Nothing of the window is kept:
+          // each of its time buckets that holds entries goes to lone_bucket_kernel, which scatters it again into u64
+          // sums (exact; as slow as that kernel is, and not met short of gains / ions far beyond BASELINE.json's)
+          block_sync();
+          clear_table(sh);
+          for (int tb = win_a + tid; tb < win_b; tb += SC_THREADS) {
+            const unsigned int upto = (unsigned int)(sh.cum[tb] >> 32), before = tb > 0 ? (unsigned int)(sh.cum[tb - 1] >> 32) : 0u;
+            if (upto == before) continue;
+            const unsigned long long slot = atomicAdd(&a.out.ctrl[CTRL_LONE], 1ull);
+            if (slot < (unsigned long long)a.out.lone_capacity) {
+              LoneBucket lb;
+              lb.event = e_local;
+              lb.tb = (uint32_t)tb;
+              a.out.lone_list[slot] = lb;
+            } else {
+              atomicMax(reinterpret_cast<unsigned int*>(&sh.ev_failed), 2u);  // list full: the bucket is lost, the host raises
+            }
+          }
+          block_sync();
+          if (tid < 64) {
+            if (tid == 0) {
+              if (sh.ev_failed == 2) {
+                sh.failed++;
+                sh.ev_failed = 1;
+              }
+              sh.retried++;
+              sh.overflow = 0;
+              sh.danger = 0;
+              sh.n_keys = 0u;
+              atomicAdd(&a.out.ctrl[CTRL_DANGER], 1ull);  // (rare: the host watches it and switches to the wide build)
+            }
+            select_window<WQ>(sh, win_b, sh.budget, lane);
+          }
+          block_sync();
+          continue;
+        }
         if (sh.overflow) {
           block_sync();
           clear_table(sh);
@@ -1592,12 +1692,12 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           unsigned int wbase = 0;
           if (lane == 0 && cnt) wbase = atomicAdd(&sh.wg_cursor, cnt);
           wbase = __shfl(wbase, 0);
-          uint32_t* __restrict__ list = reinterpret_cast<uint32_t*>(&sh.queue[0][0]);
+          unsigned short* __restrict__ list = reinterpret_cast<unsigned short*>(&sh.queue[0][0]);
 #pragma unroll
           for (int it = 0; it < ITERS; ++it) {
             const unsigned long long m = occ_mask[it];
             if ((m >> lane) & 1ull)
-              list[wbase + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(wave * PER_WAVE + it * 64 + lane);
+              list[wbase + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(wave * PER_WAVE + it * 64 + lane);
             wbase += (unsigned int)__popcll(m);
           }
         }
@@ -1652,11 +1752,11 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
         uint32_t ev_lo = (uint32_t)event, ev_hi = (uint32_t)(event >> 32);
         asm volatile("" : "+v"(ev_lo), "+v"(ev_hi));
         for (unsigned int r = tid; r < n_rows; r += SC_THREADS, prow += SC_THREADS * 3, plab += SC_THREADS) {
-          const uint32_t slot = reinterpret_cast<const uint32_t*>(&sh.queue[0][0])[r];
+          const uint32_t slot = reinterpret_cast<const unsigned short*>(&sh.queue[0][0])[r];
           const uint32_t word = sh.keys[slot];
           const unsigned long long q = sh.chg[slot];
           sh.keys[slot] = EMPTY;
-          sh.chg[slot] = 0ull;
+          sh.chg[slot] = (charge_t)0;
           const uint32_t key = word & KEY_MASK;
           const int pad = (int)(key & 0x3fffu), tb = (int)(key >> 14);
           my_charge += q;

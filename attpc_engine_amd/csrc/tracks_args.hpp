@@ -46,6 +46,7 @@ void launch_track_kernel(uint32_t blocks, size_t lds_bytes, hipStream_t s, const
 // scatter.hip compiled as it is / through scatter_small.hip (workgroups per CU: 1 / 2)
 void launch_scatter_kernel_big(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a);
 void launch_scatter_kernel_small(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a);
+void launch_scatter_kernel_wide(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a);  // scatter_wide.hip: u64 sums
 // lone.hip: the time buckets scatter_kernel recorded in out.lone_list (normally none: exits at once)
 void launch_lone_bucket_kernel(uint32_t n_workgroups, hipStream_t s, const ScatterArgs& a);
 

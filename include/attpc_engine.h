@@ -216,7 +216,9 @@ ATTPC_API int32_t attpc_set_chunk_events(attpc_ctx* ctx, int32_t chunk_events);
 ATTPC_API int32_t attpc_sync(attpc_ctx* ctx);
 /* Tuning / test switches of a context (no environment variables are read by the library):
  *   "scatter_variant"  0 = automatic, 1 = always the two-workgroups-per-CU build, 2 = always the
- *                      one-workgroup build of the scatter kernel
+ *                      one-workgroup build of the scatter kernel, 3 = always the build with u64 sums per table
+ *                      slot (the automatic choice switches to it when u32 sums -- 4.3e9 electrons per pad and
+ *                      time bucket -- turn out too small for the detector at hand)
  *   "tiny_buffers"     != 0: the next buffers are allocated far too small (exercises the
  *                      grow-and-rerun path in tests)
  *   "compact_transfer" 2 (default): delivered clouds cross PCIe as 8-byte records (attpc_unpack_rows8: the host

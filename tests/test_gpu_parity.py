@@ -516,12 +516,12 @@ def test_full_size_properties(ctx):
 
 
 def test_kernel_variants_agree():
-    """The scatter kernel exists in two builds (one 1024-thread workgroup with 8192 table slots per
-    CU, two 512-thread workgroups with 4096); the host picks one per launch.  Both give the same
-    clouds -- also where the small table meets time buckets it cannot hold (10x diffusion), which then
-    go through lone_bucket_kernel without losing a point."""
+    """The scatter kernel exists in three builds: one 1024-thread workgroup with 12 288 table slots per CU ("big"),
+    two 512-thread workgroups with 6 144 ("small") -- both with u32 sums per slot -- and one 1024-thread workgroup with
+    8 192 slots of u64 sums ("wide"); the host picks one per launch.  All give the same clouds -- also where a table
+    meets time buckets it cannot hold (10x diffusion), which then go through lone_bucket_kernel without losing a point."""
     stats = {}
-    for variant, code in (("big", 2), ("small", 1)):
+    for variant, code in (("big", 2), ("small", 1), ("wide", 3)):
         fresh = _abi.Context(0)
         fresh.set_option("scatter_variant", code)
         for name, n in (("o16aa", 3000), ("b10chain", 1500)):
@@ -530,9 +530,11 @@ def test_kernel_variants_agree():
             stats[variant, name] = eng.run(n, seed=5, first_event=11)["stats"]
         fresh.close()
     for name in ("o16aa", "b10chain"):
-        a, b = stats["big", name], stats["small", name]
-        for k in ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_failed", "n_inconsistent"):
-            assert a[k] == b[k], (name, k)
+        a = stats["big", name]
+        for other in ("small", "wide"):
+            b = stats[other, name]
+            for k in ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_failed", "n_inconsistent"):
+                assert a[k] == b[k], (name, other, k)
         assert a["n_failed"] == 0 and a["n_inconsistent"] == 0
     print("lone buckets (big / small, b10chain):", stats["big", "b10chain"]["n_lone_buckets"],
           stats["small", "b10chain"]["n_lone_buckets"])
@@ -638,6 +640,44 @@ def test_hint_next_is_only_a_scheduling_hint():
             assert again[k] == plain_b[k], k
     finally:
         fresh.close()
+
+
+def test_sums_beyond_u32_switch_to_the_wide_table(orc):
+    """The default scatter builds keep u32 electrons per table slot; every add returns the old sum, and a window in which
+    a sum reached 2^31 is thrown away and scattered again, bucket by bucket, by lone_bucket_kernel (u64 sums).  With a gain
+    of 2e6 (11x the AT-TPC's) hundreds of keys per event pass 2^31:
+    (i) the narrow builds forced (`scatter_variant` 1 / 2: no automatic switch): every dangerous window goes through
+    lone_bucket_kernel -- clouds equal the oracle's;  (ii) automatic: the context switches to the build with u64 sums by
+    itself and repeats the launch -- clouds equal the oracle's, no lone bucket left in the accepted launches;
+    (iii) the wide build forced from the start: the same."""
+    import copy
+    from attpc_engine_amd.detector.simulator import simulate_batch
+    base = Inputs("o16aa")
+    inp = copy.copy(base)
+    inp.config = copy.copy(base.config)
+    inp.config.det_params = copy.copy(base.config.det_params)
+    inp.config.det_params.mpgd_gain = 2_000_000
+    inp = _rebuild(inp)
+    seed, first, n = 13, 40, 24
+    vertex, p4, _, _ = orc.kin_batch(inp.kin, seed, first, n, threads=8)
+    refs = [orc.simulate(inp.det_raw, inp.layout, seed, first + e, p4[e], vertex[e], capacity=1 << 19) for e in range(n)]
+    assert sum(int((r[0][:, 2] >= 2.0 ** 31).sum()) for r in refs) > 100
+    lone = {}
+    for variant in (2, 1, 0, 3):
+        fresh = _abi.Context(0)
+        try:
+            fresh.set_option("scatter_variant", variant)
+            offsets, points, labels, stats = simulate_batch(p4, vertex, inp.z, inp.a, inp.config, seed, inp.indices,
+                                                            first_event=first, ctx=fresh)
+            assert stats["n_failed"] == 0 and stats["n_inconsistent"] == 0
+            for e in range(n):
+                compare_clouds(*sort_cloud(points[offsets[e]:offsets[e + 1]], labels[offsets[e]:offsets[e + 1]]),
+                               *sort_cloud(refs[e][0], refs[e][1]))
+            lone[variant] = stats["n_lone_buckets"]
+        finally:
+            fresh.close()
+    print("lone buckets: big narrow", lone[2], "small narrow", lone[1], "automatic", lone[0], "wide", lone[3])
+    assert lone[2] > 0 and lone[1] > 0 and lone[0] == 0 and lone[3] == 0
 
 
 def test_fetch_with_block_reserved_rows(ctx):

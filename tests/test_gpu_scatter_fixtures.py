@@ -113,7 +113,7 @@ def test_scatter_kernel_vs_reference_transport(golden_dir, ctx, name):
     _configure(ctx, float(g[f"{name}_diffusion"]))
     cases = [(g[f"{name}_xyt{i}"], g[f"{name}_electrons{i}"], int(g[f"{name}_label{i}"]))
              for i in range(int(g[f"{name}_n_cases"]))]
-    for variant in (1, 2):  # both builds of the kernel
+    for variant in (1, 2, 3):  # the three builds of the kernel (u32 sums: two / one workgroup per CU; u64 sums)
         ctx.set_option("scatter_variant", variant)
         (cloud,), stats = device_scatter(ctx, [cases])
         tbpad = g[f"{name}_tbpad"]
@@ -227,11 +227,13 @@ def _plane_filling_event(cfg, n_tracks=4, pitch_mm=4.0, tb=500.25, electrons=3_0
             for p, lab in zip(parts, labels)]
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-def test_lone_time_bucket_larger_than_the_lds_table(ctx, orc, variant):
-    """One time bucket of one event lights > 8192 pads -- more than either LDS table holds.  The
-    reference's dict has no limit (simulator.py:93-101); the bucket goes through lone_bucket_kernel's
-    direct-mapped table and the cloud equals the oracle's, beside ordinary events in the same launch."""
+@pytest.mark.parametrize("variant,must_be_lone", [(1, True), (3, True), (2, False)])
+def test_lone_time_bucket_larger_than_the_lds_table(ctx, orc, variant, must_be_lone):
+    """One time bucket of one event lights > 8192 pads -- more than the 6144-slot table of the two-workgroup build (1)
+    and the 8192-slot table of the u64 build (3) hold.  The reference's dict has no limit (simulator.py:93-101); the
+    bucket goes through lone_bucket_kernel's direct-mapped table and the cloud equals the oracle's, beside ordinary
+    events in the same launch.  (The one-workgroup build (2) has 12 288 slots since round 3, more than the pad plane has
+    pads: it may hold the bucket; the cloud is checked either way.)"""
     cfg, raw, keep = _configure(ctx, 0.277)
     big = _plane_filling_event(cfg)
     small = [(xyt[:40] * np.array([1.0, 1.0, 0.5]), el[:40], lab) for xyt, el, lab in big]  # tb 250: an ordinary event
@@ -240,7 +242,8 @@ def test_lone_time_bucket_larger_than_the_lds_table(ctx, orc, variant):
         clouds, stats = device_scatter(ctx, [small, big, small])
     finally:
         ctx.set_option("scatter_variant", 0)
-    assert stats["n_failed"] == 0 and stats["n_inconsistent"] == 0 and stats["n_lone_buckets"] >= 1
+    assert stats["n_failed"] == 0 and stats["n_inconsistent"] == 0
+    assert stats["n_lone_buckets"] >= 1 or not must_be_lone
     for ev, (pts, lab) in zip([small, big, small], clouds):
         keys, charge, labels = orc.transport(raw, ev)
         tb, pad = np.array([orc.unpair(int(k)) for k in keys], dtype=np.int64).T

@@ -8,5 +8,5 @@ C="$ROOT/attpc_engine_amd/csrc"
 NAME=$1
 shift
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden "$@" -I"$ROOT/include" -I"$C" \
-  -o "$ROOT/attpc_engine_amd/_lib/libattpc_$NAME.so" "$C/abi.hip" "$C/kinematics.hip" "$C/tracks.hip" "$C/scatter.hip" "$C/scatter_small.hip" "$C/lone.hip" "$C/spyral.hip" "$C/unpack_host.cpp"
+  -o "$ROOT/attpc_engine_amd/_lib/libattpc_$NAME.so" "$C/abi.hip" "$C/kinematics.hip" "$C/tracks.hip" "$C/scatter.hip" "$C/scatter_small.hip" "$C/scatter_wide.hip" "$C/lone.hip" "$C/spyral.hip" "$C/unpack_host.cpp"
 echo "built $ROOT/attpc_engine_amd/_lib/libattpc_$NAME.so"

@@ -184,6 +184,24 @@ __device__ __forceinline__ int key_estimate(int tb, float spread) {
   const float r = 1.0f + sqrtf(spread * (float)tb);
   return (int)fminf(r * r + 0.5f, 100.0f);  // a sample has 100 pixels
 }
+// ... refined (round 3): a key holds its time bucket, so a sample shares pads-as-keys only with samples of its own
+// bucket -- and with its predecessor on the track, if that one is in the same bucket, it shares all the pads the two
+// meshes have in common: only the strip the mesh moved on by is new, about (S + p) d / p^2 pads for a displacement d
+// (S = 6 sigma_t, p = 4.9 mm).  The slow heavy recoils of the headline workload put several samples into every bucket:
+// the plain estimate was twice the keys the windows really held (tables a quarter full instead of half); samples
+// 0.1 mm apart (configs[4]) share nearly everything.  `rec` = the sample's record (x, y, time bucket, electrons),
+// `prev` = its predecessor's or nullptr.
+__device__ __forceinline__ int key_estimate_on_track(const double* rec, const double* prev, double t, int tb_of_entry,
+                                                     double prev_ts, float spread) {
+  const float r = 1.0f + sqrtf(spread * (float)(int)fmin(t, 511.0));
+  float est = r * r;
+  if (prev != nullptr && prev_ts >= 0.0 && (int)prev_ts == tb_of_entry) {
+    const float dx = (float)(rec[0] - prev[0]), dy = (float)(rec[1] - prev[1]);
+    const float d_over_p = sqrtf(dx * dx + dy * dy) * (1.0f / 4.9e-3f);
+    est = fminf(est, r * d_over_p + 1.0f);
+  }
+  return (int)fminf(est + 0.5f, 100.0f);
+}
 
 // Monte-Carlo diffusion extension: what a staged entry needs instead of the mesh indices (these
 // records overlay st_ix / st_iy)
@@ -703,6 +721,14 @@ __device__ __forceinline__ void select_window(ScatterShared& sh, int from, int b
   }
   int b0 = wave_upper_bound<false>(sh.cum, a0, ATTPC_NUM_TB, keys0 + (unsigned int)budget, ln);
   if (b0 <= a0) b0 = a0 + 1;
+  // What is left of the event fits this window with a little stretch: take it all, rather than leave a remainder
+  // window that costs its own selection, staging round, barriers and flush for a fraction of a pass (round 3: an event
+  // of 3 1/4 windows' worth of keys was cut into 3 whole-pass windows + the quarter).
+#ifndef ATTPC_SC_TAIL_PCT
+#define ATTPC_SC_TAIL_PCT 25
+#endif
+  if ((unsigned int)sh.cum[ATTPC_NUM_TB - 1] - keys0 <= (unsigned int)budget + (unsigned int)budget * ATTPC_SC_TAIL_PCT / 100u)
+    b0 = ATTPC_NUM_TB;
   const unsigned int entries = (unsigned int)(sh.cum[b0 - 1] >> 32) - entries0;
   const unsigned int passes = QUANTUM == SC_THREADS / MESH ? entries * MESH / SC_THREADS : entries / (unsigned int)QUANTUM;
   if (passes >= 1u && (unsigned int)(sh.cum[ATTPC_NUM_TB - 1] >> 32) > entries0 + entries) {
@@ -852,21 +878,29 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
         // the list; later passes never touch the block table again.
         for (int e0 = 0; e0 < total_s; e0 += 2 * SC_THREADS) {  // two entries per thread in flight
           const double* rec[2];
+          const double* prev[2];
           int isim[2], sl[2];
-          double t[2];
+          double t[2], t_prev[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int e = e0 + u * SC_THREADS + tid;
             sl[u] = 0;
             isim[u] = 0;
             rec[u] = arena;
+            prev[u] = nullptr;
             if (e < total_s) {
               sl[u] = n_slices == 1 ? 0 : e / total;
-              rec[u] = sample_ptr(sh, arena, ev_table, e - sl[u] * total, isim[u]);
+              const int c = e - sl[u] * total;
+              rec[u] = sample_ptr(sh, arena, ev_table, c, isim[u]);
+              int isim_prev;
+              if (c > sh.cnt[isim[u]]) prev[u] = sample_ptr(sh, arena, ev_table, c - 1, isim_prev);  // same track
             }
           }
 #pragma unroll
-          for (int u = 0; u < 2; ++u) t[u] = rec[u][2];
+          for (int u = 0; u < 2; ++u) {
+            t[u] = rec[u][2];
+            t_prev[u] = prev[u] != nullptr ? prev[u][2] : -1.0;
+          }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int e = e0 + u * SC_THREADS + tid;
@@ -876,7 +910,9 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
               const double ts = slice_time(a.det, t[u], sl[u], n_slices);
               if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
                 meta = (uint32_t)(int)ts | ((uint32_t)isim[u] << 10) | ((uint32_t)sl[u] << 13);
-                atomicAdd(&sh.cum[(int)ts], (1ull << 32) | (unsigned long long)key_estimate((int)fmin(t[u], 511.0), spread));
+                const double prev_ts = t_prev[u] >= 0.0 ? slice_time(a.det, t_prev[u], sl[u], n_slices) : -1.0;
+                atomicAdd(&sh.cum[(int)ts], (1ull << 32) | (unsigned long long)key_estimate_on_track(rec[u], prev[u], t[u], (int)ts,
+                                                                                                    prev_ts, spread));
               }
             }
             mg_list[e] = make_uint2((uint32_t)((rec[u] - arena) >> 2), meta);
@@ -893,13 +929,20 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           const int cs = tid + k * SC_THREADS;
           if (cs < total_s) {
             const int c = cs / n_slices;
-            int isim;
-            const double t = sample_ptr(sh, arena, nullptr, c, isim)[2];
+            int isim, isim_prev;
+            const double* rec = sample_ptr(sh, arena, nullptr, c, isim);
+            // (the predecessor on the same track: c - 1 unless c is the track's first sample)
+            const double* prev = c > sh.cnt[isim] ? sample_ptr(sh, arena, nullptr, c - 1, isim_prev) : nullptr;
+            const double t = rec[2];
+            const double t_prev = prev != nullptr ? prev[2] : -1.0;
             if (t >= 0.0) {
-              const double ts = slice_time(a.det, t, cs - c * n_slices, n_slices);
+              const int sl = cs - c * n_slices;
+              const double ts = slice_time(a.det, t, sl, n_slices);
               if (ts >= 0.0 && ts < (double)ATTPC_NUM_TB) {
                 my_tb[k] = (int)ts;
-                atomicAdd(&sh.cum[my_tb[k]], (1ull << 32) | (unsigned long long)key_estimate((int)fmin(t, 511.0), spread));
+                const double prev_ts = t_prev >= 0.0 ? slice_time(a.det, t_prev, sl, n_slices) : -1.0;
+                atomicAdd(&sh.cum[my_tb[k]],
+                          (1ull << 32) | (unsigned long long)key_estimate_on_track(rec, prev, t, my_tb[k], prev_ts, spread));
               }
             }
           }
@@ -1751,6 +1794,10 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
         int64_t* plab = a.out.labels + (base + (unsigned long long)tid);
         uint32_t ev_lo = (uint32_t)event, ev_hi = (uint32_t)(event >> 32);
         asm volatile("" : "+v"(ev_lo), "+v"(ev_hi));
+#ifndef ATTPC_SC_FLUSH_UNROLL
+#define ATTPC_SC_FLUSH_UNROLL 1
+#endif
+#pragma unroll ATTPC_SC_FLUSH_UNROLL
         for (unsigned int r = tid; r < n_rows; r += SC_THREADS, prow += SC_THREADS * 3, plab += SC_THREADS) {
           const uint32_t slot = reinterpret_cast<const unsigned short*>(&sh.queue[0][0])[r];
           const uint32_t word = sh.keys[slot];

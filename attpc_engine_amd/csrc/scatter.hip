@@ -1721,27 +1721,40 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
         }
         block_sync();
         PHASE_MARK(19);
-        {  // every wave compacts its own contiguous slice of the table with a single LDS atomic
+        {  // every wave compacts its own contiguous slice of the table with a single LDS atomic.  A lane looks at four
+           // consecutive slots per step (one 16-byte read), counts its occupied ones, gets its place in the wave's
+           // part of the slot list from a ballot prefix of those counts (0..12: four bits) and writes them there:
+           // 3 reads + 4 ballots per wave and window where the slot-per-lane version took 12 + 12 (compaction was 8 %
+           // of the kernel's instructions with the 6 144-slot table).
           constexpr int PER_WAVE = HASH_CAP / N_WAVES;
-          constexpr int ITERS = PER_WAVE / 64;
+          constexpr int STEPS = PER_WAVE / 256;
+          static_assert(PER_WAVE % 256 == 0 && STEPS * 4 < 16, "four slots per lane and step; a lane's count fits four bits");
           const int wave = tid >> 6;
-          unsigned long long occ_mask[ITERS];
-          unsigned int cnt = 0;
+          uint32_t occ = 0u;  // bit 4 * step + k: slot k of this lane's four of that step is occupied
 #pragma unroll
-          for (int it = 0; it < ITERS; ++it) {
-            occ_mask[it] = __ballot(sh.keys[wave * PER_WAVE + it * 64 + lane] != EMPTY);
-            cnt += (unsigned int)__popcll(occ_mask[it]);
+          for (int st = 0; st < STEPS; ++st) {
+            const uint4 k4 = *reinterpret_cast<const uint4*>(&sh.keys[wave * PER_WAVE + st * 256 + lane * 4]);
+            occ |= ((k4.x != EMPTY ? 1u : 0u) | (k4.y != EMPTY ? 2u : 0u) | (k4.z != EMPTY ? 4u : 0u) | (k4.w != EMPTY ? 8u : 0u)) << (4 * st);
+          }
+          const uint32_t mine = (uint32_t)__popc(occ);
+          unsigned int before = 0u, cnt = 0u;
+#pragma unroll
+          for (int bit = 0; bit < 4; ++bit) {
+            const unsigned long long mk = __ballot((mine >> bit) & 1u);
+            before += (unsigned int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u)) << bit;
+            cnt += (unsigned int)__popcll(mk) << bit;
           }
           unsigned int wbase = 0;
           if (lane == 0 && cnt) wbase = atomicAdd(&sh.wg_cursor, cnt);
           wbase = __shfl(wbase, 0);
           unsigned short* __restrict__ list = reinterpret_cast<unsigned short*>(&sh.queue[0][0]);
+          unsigned int pos = wbase + before;
 #pragma unroll
-          for (int it = 0; it < ITERS; ++it) {
-            const unsigned long long m = occ_mask[it];
-            if ((m >> lane) & 1ull)
-              list[wbase + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(wave * PER_WAVE + it * 64 + lane);
-            wbase += (unsigned int)__popcll(m);
+          for (int st = 0; st < STEPS; ++st) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if ((occ >> (4 * st + k)) & 1u) list[pos++] = (unsigned short)(wave * PER_WAVE + st * 256 + lane * 4 + k);
+            }
           }
         }
         PHASE_MARK(15);  // compaction done (wave 0)

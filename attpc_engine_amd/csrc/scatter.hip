@@ -1748,12 +1748,19 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           if (lane == 0 && cnt) wbase = atomicAdd(&sh.wg_cursor, cnt);
           wbase = __shfl(wbase, 0);
           unsigned short* __restrict__ list = reinterpret_cast<unsigned short*>(&sh.queue[0][0]);
+          // (branch-free: a free slot's "entry" goes to a dump position behind the list -- twelve short store sequences
+          //  instead of twelve exec-mask branches)
+          constexpr unsigned int DUMP = (unsigned int)(sizeof(sh.queue) / sizeof(unsigned short)) - 1u;
+          static_assert(sizeof(sh.queue) / sizeof(unsigned short) > HASH_CAP, "room for the dump position behind the slot list");
           unsigned int pos = wbase + before;
+          const unsigned int first = (unsigned int)(wave * PER_WAVE + lane * 4);
 #pragma unroll
           for (int st = 0; st < STEPS; ++st) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              if ((occ >> (4 * st + k)) & 1u) list[pos++] = (unsigned short)(wave * PER_WAVE + st * 256 + lane * 4 + k);
+              const unsigned int bit = (occ >> (4 * st + k)) & 1u;
+              list[bit ? pos : DUMP] = (unsigned short)(first + (unsigned int)(st * 256 + k));
+              pos += bit;
             }
           }
         }
@@ -1807,10 +1814,6 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
         int64_t* plab = a.out.labels + (base + (unsigned long long)tid);
         uint32_t ev_lo = (uint32_t)event, ev_hi = (uint32_t)(event >> 32);
         asm volatile("" : "+v"(ev_lo), "+v"(ev_hi));
-#ifndef ATTPC_SC_FLUSH_UNROLL
-#define ATTPC_SC_FLUSH_UNROLL 1
-#endif
-#pragma unroll ATTPC_SC_FLUSH_UNROLL
         for (unsigned int r = tid; r < n_rows; r += SC_THREADS, prow += SC_THREADS * 3, plab += SC_THREADS) {
           const uint32_t slot = reinterpret_cast<const unsigned short*>(&sh.queue[0][0])[r];
           const uint32_t word = sh.keys[slot];

@@ -78,9 +78,12 @@ __device__ __forceinline__ void rng_pair(uint64_t seed, uint64_t event, uint32_t
 // A pure function of (seed, global event id, time bucket, pad), like every other draw; event ids 2^40 apart share
 // their jitter streams (nothing else).  The plain-C oracle and the host expansion of the 8-byte transfer record
 // (unpack_host.cpp) compute the identical value.
-__device__ __forceinline__ double jitter_uniform(uint32_t seed_lo, uint32_t seed_hi, uint32_t ev_lo, uint32_t ev_hi, uint32_t key) {
+__host__ __device__ __forceinline__ uint32_t jitter_key_word(uint32_t seed_lo, uint32_t seed_hi) {
+  return seed_lo ^ ((seed_hi << 13) | (seed_hi >> 19)) ^ DOMAIN_JITTER;
+}
+// (`k` = jitter_key_word(seed): a per-launch constant the flush loop keeps in one scalar register)
+__device__ __forceinline__ double jitter_uniform_k(uint32_t k, uint32_t ev_lo, uint32_t ev_hi, uint32_t key) {
   uint32_t c0 = ev_lo, c1 = (ev_hi << 24) | key;
-  uint32_t k = seed_lo ^ ((seed_hi << 13) | (seed_hi >> 19)) ^ DOMAIN_JITTER;
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
     uint32_t hi, lo;
@@ -90,6 +93,9 @@ __device__ __forceinline__ double jitter_uniform(uint32_t seed_lo, uint32_t seed
     k += 0x9E3779B9u;
   }
   return u53(c0, c1);
+}
+__device__ __forceinline__ double jitter_uniform(uint32_t seed_lo, uint32_t seed_hi, uint32_t ev_lo, uint32_t ev_hi, uint32_t key) {
+  return jitter_uniform_k(jitter_key_word(seed_lo, seed_hi), ev_lo, ev_hi, key);
 }
 
 // Box-Muller, cosine branch, on (1 - ua) in (0, 1]

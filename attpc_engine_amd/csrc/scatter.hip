@@ -1814,6 +1814,8 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
         int64_t* plab = a.out.labels + (base + (unsigned long long)tid);
         uint32_t ev_lo = (uint32_t)event, ev_hi = (uint32_t)(event >> 32);
         asm volatile("" : "+v"(ev_lo), "+v"(ev_hi));
+        const uint32_t jitter_word =
+            (uint32_t)__builtin_amdgcn_readfirstlane((int)jitter_key_word((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
         for (unsigned int r = tid; r < n_rows; r += SC_THREADS, prow += SC_THREADS * 3, plab += SC_THREADS) {
           const uint32_t slot = reinterpret_cast<const unsigned short*>(&sh.queue[0][0])[r];
           const uint32_t word = sh.keys[slot];
@@ -1825,12 +1827,12 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           my_charge += q;
           my_keys += (((unsigned long long)ev_hi << 32 | ev_lo) << 24) + (unsigned long long)key;
           if (base != ~0ull) {
-            // The seed goes through an opaque asm per row: the Philox round keys are then scalar adds inside
-            // the loop instead of scalar registers held (and, at the limit of 102, spilled to vector lanes
-            // and read back with a VALU instruction each) across the whole kernel
-            uint32_t seed_lo = (uint32_t)a.seed, seed_hi = (uint32_t)(a.seed >> 32);
-            asm volatile("" : "+s"(seed_lo), "+s"(seed_hi));
-            const double ua = jitter_uniform(seed_lo, seed_hi, ev_lo, ev_hi, key);  // simulator.py:108
+            // The key word goes through an opaque asm per row: the Philox round keys are then scalar adds inside the
+            // loop instead of scalar registers held (and, at the limit of 102, spilled to vector lanes and read back
+            // with a VALU instruction each) across the whole kernel
+            uint32_t jkey = jitter_word;
+            asm volatile("" : "+s"(jkey));
+            const double ua = jitter_uniform_k(jkey, ev_lo, ev_hi, key);  // simulator.py:108
             prow[0] = (double)pad;
             prow[1] = (double)tb + ua;
             prow[2] = (double)q;

@@ -95,7 +95,8 @@ struct attpc_ctx {
   int device = 0;
   int n_cus = 256;                 // compute units
   hipStream_t stream = nullptr;    // S
-  hipStream_t stream_t = nullptr;  // T
+  hipStream_t stream_t = nullptr;  // T (== stream when the option "serial_tracks" is on)
+  hipStream_t stream_t_own = nullptr;  // the low-priority stream the context created
   hipStream_t stream_c = nullptr;  // C
   std::string error;
   int32_t chunk_events = 65536;
@@ -106,6 +107,8 @@ struct attpc_ctx {
   int opt_unpack_threads = 0;      // 0: min(32, half of the hardware threads)
   int opt_deliver_chunk = 8192;    // events per chunk when clouds are delivered (the pipeline's fill and drain time)
   int opt_merge = -1;              // scatter kernel's merge variant: -1 automatic (path-length dE/dx step), 0 never, 1 always
+  int opt_first_batch_chunks = 0;  // > 0: the first track batch of a call spans at most this many scatter chunks
+  int opt_serial_tracks = -1;      // -1 automatic (see pick_track_stream), 0 beside the scatter launches, 1 behind them
 
   bool kin_ready = false;
   attpc_kin_desc kin{};            // device pointers inside
@@ -239,6 +242,17 @@ bool same_layout(const attpc_event_layout& a, const attpc_event_layout& b) {
   for (int i = 0; i < a.n_rows; ++i)
     if (a.species_of_row[i] != b.species_of_row[i]) return false;
   return true;
+}
+
+// Where the kinematics + tracks of the NEXT batch run while the current one is scattered: on the scatter stream itself,
+// behind its launches (serial), or beside them on the low-priority stream.  Both kernels are bound by instruction issue;
+// beside the default scatter kernel the track kernel (170 VGPRs, 2 waves per SIMD) displaces co-resident scatter
+// workgroups and costs more than it hides (headline: 171.6 ms per step beside, 166.5 behind) -- beside the merge variant
+// of the path-length step, where track integration is a quarter of the device time and the scatter kernel leaves more
+// idle issue slots, it pays (configs[4]: 1.80e5 events/s beside, 1.61e5 behind).  Nothing may be in flight when it changes.
+void pick_track_stream(attpc_ctx* ctx) {
+  const bool serial = ctx->opt_serial_tracks >= 0 ? ctx->opt_serial_tracks != 0 : !(ctx->det_ready && ctx->det.path_step > 0.0);
+  ctx->stream_t = serial ? ctx->stream : ctx->stream_t_own;
 }
 
 int32_t validate_layout(attpc_ctx* ctx, const attpc_event_layout* lay, bool with_species) {
@@ -1108,6 +1122,9 @@ int32_t run_events(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t
     const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events);
     uint64_t want = track_batch_events(ctx, lay, chunk);
     if (ctx->blocks_per_track <= 0.0) want = std::min<uint64_t>(want, std::min<uint64_t>(chunk, 16384));  // pilot: sizes the arena
+    // the first batch of a call is integrated with nothing to run beside: a shorter one (opt_first_batch_chunks scatter
+    // chunks) leaves less of the call's track time exposed
+    else if (at == 0 && ctx->opt_first_batch_chunks > 0) want = std::min<uint64_t>(want, chunk * (uint64_t)ctx->opt_first_batch_chunks);
     return (uint32_t)std::min<uint64_t>(want, n_events - at);
   };
   // the caller's announcement of the call AFTER this one (attpc_sim_hint_next) belongs to this run alone
@@ -1217,7 +1234,8 @@ int32_t attpc_ctx_create(int32_t device, attpc_ctx** out) {
   int prio_low = 0, prio_high = 0;
   if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_low = prio_high = 0;
   ok = ok && hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_high) == hipSuccess;
-  ok = ok && hipStreamCreateWithPriority(&ctx->stream_t, hipStreamNonBlocking, prio_low) == hipSuccess;
+  ok = ok && hipStreamCreateWithPriority(&ctx->stream_t_own, hipStreamNonBlocking, prio_low) == hipSuccess;
+  pick_track_stream(ctx);
   ok = ok && hipStreamCreateWithPriority(&ctx->stream_c, hipStreamNonBlocking, prio_high) == hipSuccess;
   auto make_event = [&](hipEvent_t* e) { ok = ok && hipEventCreate(e) == hipSuccess; };
   for (TrackSet& ts : ctx->tset) {
@@ -1248,7 +1266,7 @@ int32_t attpc_ctx_destroy(attpc_ctx* ctx) {
   }
   ctx->unpack_cv.notify_all();
   if (ctx->unpacker.joinable()) ctx->unpacker.join();
-  if (ctx->stream_t) (void)hipStreamSynchronize(ctx->stream_t);
+  if (ctx->stream_t_own) (void)hipStreamSynchronize(ctx->stream_t_own);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream_c) (void)hipStreamSynchronize(ctx->stream_c);
   free_all(ctx->kin_allocs);
@@ -1284,7 +1302,7 @@ int32_t attpc_ctx_destroy(attpc_ctx* ctx) {
   if (ctx->h_out_ctrl) (void)hipHostFree(ctx->h_out_ctrl);
   for (void* p : ctx->host_allocs) (void)hipHostFree(p);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  if (ctx->stream_t) (void)hipStreamDestroy(ctx->stream_t);
+  if (ctx->stream_t_own) (void)hipStreamDestroy(ctx->stream_t_own);
   if (ctx->stream_c) (void)hipStreamDestroy(ctx->stream_c);
   delete ctx;
   return ATTPC_OK;
@@ -1315,6 +1333,19 @@ int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value) {
   } else if (key == "unpack_threads") {
     if (value < 0 || value > 1024) return fail(ctx, ATTPC_E_INVALID, "unpack_threads must be 0..1024");
     ctx->opt_unpack_threads = (int)value;
+  } else if (key == "serial_tracks") {
+    // != 0: kinematics + track integration of the next batch are queued on the scatter stream, behind the current
+    // batch's scatter launches, instead of beside them on the low-priority stream
+    int32_t rcs = drop_prefetch(ctx);
+    if (rcs) return rcs;
+    if ((rcs = sync_all(ctx))) return rcs;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_t_own));
+    if (value < -1 || value > 1) return fail(ctx, ATTPC_E_INVALID, "serial_tracks must be -1, 0 or 1");
+    ctx->opt_serial_tracks = (int)value;
+    pick_track_stream(ctx);
+  } else if (key == "first_batch_chunks") {
+    if (value < 0 || value > MAX_SLOTS) return fail(ctx, ATTPC_E_INVALID, "first_batch_chunks must be 0..8");
+    ctx->opt_first_batch_chunks = (int)value;
   } else if (key == "scatter_merge") {
     if (value < -1 || value > 1) return fail(ctx, ATTPC_E_INVALID, "scatter_merge must be -1, 0 or 1");
     ctx->opt_merge = (int)value;
@@ -1582,6 +1613,8 @@ int32_t attpc_det_configure(attpc_ctx* ctx, const attpc_det_desc* d) {
   if ((rc = upload(ctx, ctx->det_allocs, tabs.data(), tabs.size(), &dv.dedx))) return rc;
   ctx->det = dv;
   ctx->det_ready = true;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_t_own));  // (sync_all above covered stream_t, whichever it was)
+  pick_track_stream(ctx);
   return ATTPC_OK;
 }
 

@@ -68,6 +68,8 @@ def parse_args(argv=None) -> argparse.Namespace:
                          "measured slower (197.4 against 192.7 ms per 1e6-event step, profiles/r03_hint_ab.md) -- both "
                          "kernels are issue bound, and the scatter launches lose more beside the track kernel than the "
                          "8 ms the track batch takes alone")
+    ap.add_argument("--first-batch-chunks", type=int, default=-1, help="engine option first_batch_chunks (experiment)")
+    ap.add_argument("--serial-tracks", type=int, default=None, help="engine option serial_tracks (A/B: 0 / 1; default automatic)")
     ap.add_argument("--stub-engine", action="store_true",
                     help="TEST ONLY: no GPU, no library -- a stand-in engine with made-up statistics, so that the "
                          "launcher / sharding / reduction path runs on a CPU box; the line says data = 'stub'")
@@ -166,6 +168,10 @@ def main(argv=None) -> int:
         n_dev = max(1, _abi.load_library().attpc_device_count())
         ctx = _abi.Context(local_rank % n_dev)  # one rank per GPU; wraps only when rehearsing on fewer GPUs
         engine = Engine(pipeline, config, indices, context=ctx, chunk_events=args.chunk_events or None)
+        if args.first_batch_chunks >= 0:
+            ctx.set_option("first_batch_chunks", args.first_batch_chunks)
+        if args.serial_tracks is not None:
+            ctx.set_option("serial_tracks", args.serial_tracks)
     strong = args.global_events > 0
     step_events = args.global_events if strong else args.events * world_size  # events of one step over all ranks
 

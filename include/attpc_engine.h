@@ -231,6 +231,11 @@ ATTPC_API int32_t attpc_sync(attpc_ctx* ctx);
  *   "deliver_chunk_events"  events per chunk when clouds are delivered (default 8192: a chunk's copy hides the next
  *                      chunk's scatter and assembly; the first chunk's device work and the last chunk's expansion
  *                      stand alone, so smaller chunks shorten a short call)
+ *   "serial_tracks"    1: kinematics + track integration of the next batch run on the scatter stream, behind the
+ *                      current batch's scatter launches; 0: beside them on a low-priority stream; -1 (default):
+ *                      behind on the reference's time grid (beside is 3 % slower there: both kernels are issue
+ *                      bound), beside with the path-length dE/dx step (12 % faster there)
+ *   "first_batch_chunks"  > 0: the first track batch of a call spans at most this many scatter chunks (experiment)
  *   "scatter_merge"    -1 (default) = automatic, 0 = never, 1 = always use the scatter kernel's merge variant, which adds
  *                      up the pixel charges of consecutive track samples that fall on the same pad in the same time
  *                      bucket before the table sees them (same results; automatic = with the path-length dE/dx step,

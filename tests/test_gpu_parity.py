@@ -680,6 +680,28 @@ def test_sums_beyond_u32_switch_to_the_wide_table(orc):
     assert lone[2] > 0 and lone[1] > 0 and lone[0] == 0 and lone[3] == 0
 
 
+def test_scheduling_options_do_not_change_results():
+    """Where the next batch's tracks run (behind / beside the scatter launches: `serial_tracks`) and how long a call's
+    first track batch is (`first_batch_chunks`) are scheduling choices: same checksums for every setting."""
+    fresh = _abi.Context(0)
+    try:
+        eng = _engine(Inputs("o16aa"), fresh, chunk_events=1024)
+        got = {}
+        for serial in (-1, 0, 1):
+            for first in (0, 1):
+                fresh.set_option("serial_tracks", serial)
+                fresh.set_option("first_batch_chunks", first)
+                got[serial, first] = eng.run(20_000, seed=9, first_event=5)["stats"]
+        base = got[-1, 0]
+        assert base["n_points"] > 0 and base["launches_tracks"] >= 2
+        for key, st in got.items():
+            for k in ("n_points", "n_track_samples", "charge_checksum", "key_checksum", "n_failed", "n_inconsistent"):
+                assert st[k] == base[k], (key, k)
+        assert got[0, 1]["launches_tracks"] > got[0, 0]["launches_tracks"]  # the short first batch adds a launch
+    finally:
+        fresh.close()
+
+
 def test_fetch_with_block_reserved_rows(ctx):
     """A launch large enough for block-wise row reservations (holes between the workgroups' blocks):
     the gathered CSR cloud reproduces the device-side checksums, so no row is lost or doubled."""

@@ -108,6 +108,7 @@ struct attpc_ctx {
   int opt_deliver_chunk = 8192;    // events per chunk when clouds are delivered (the pipeline's fill and drain time)
   int opt_merge = -1;              // scatter kernel's merge variant: -1 automatic (path-length dE/dx step), 0 never, 1 always
   int opt_first_batch_chunks = 0;  // > 0: the first track batch of a call spans at most this many scatter chunks
+  int opt_track_blocks_per_cu = 8; // track_kernel workgroups (256 threads) launched per CU at most
   int opt_serial_tracks = -1;      // -1 automatic (see pick_track_stream), 0 beside the scatter launches, 1 behind them
 
   bool kin_ready = false;
@@ -422,7 +423,7 @@ int32_t launch_tracks(attpc_ctx* ctx, TrackSet& ts, const TrackLaunch& tl) {
     if ((rc = ensure(ctx, ts.n_steps, alloc_tracks * sizeof(int32_t)))) return rc;
     const size_t lds = (size_t)ctx->det.n_species * ATTPC_DEDX_NODES * sizeof(double);
     const uint32_t waves_needed = (n_tracks + 63) / 64;
-    const uint32_t blocks = std::min<uint32_t>((waves_needed + 3) / 4, (uint32_t)ctx->n_cus * 8u);
+    const uint32_t blocks = std::min<uint32_t>((waves_needed + 3) / 4, (uint32_t)ctx->n_cus * (uint32_t)ctx->opt_track_blocks_per_cu);
     // every wave reserves arena blocks 64 at a time: that slack comes on top of what the samples need
     // keep the arena while it covers the observed need with 3 % to spare, grow it by 25 % when it does not:
     // the need per track moves by fractions of a percent from batch to batch, and re-allocating tens of GB
@@ -1343,6 +1344,9 @@ int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value) {
     if (value < -1 || value > 1) return fail(ctx, ATTPC_E_INVALID, "serial_tracks must be -1, 0 or 1");
     ctx->opt_serial_tracks = (int)value;
     pick_track_stream(ctx);
+  } else if (key == "track_blocks_per_cu") {
+    if (value < 1 || value > 64) return fail(ctx, ATTPC_E_INVALID, "track_blocks_per_cu must be 1..64");
+    ctx->opt_track_blocks_per_cu = (int)value;
   } else if (key == "first_batch_chunks") {
     if (value < 0 || value > MAX_SLOTS) return fail(ctx, ATTPC_E_INVALID, "first_batch_chunks must be 0..8");
     ctx->opt_first_batch_chunks = (int)value;

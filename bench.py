@@ -69,6 +69,7 @@ def parse_args(argv=None) -> argparse.Namespace:
                          "kernels are issue bound, and the scatter launches lose more beside the track kernel than the "
                          "8 ms the track batch takes alone")
     ap.add_argument("--first-batch-chunks", type=int, default=-1, help="engine option first_batch_chunks (experiment)")
+    ap.add_argument("--track-blocks-per-cu", type=int, default=None, help="engine option track_blocks_per_cu (experiment)")
     ap.add_argument("--serial-tracks", type=int, default=None, help="engine option serial_tracks (A/B: 0 / 1; default automatic)")
     ap.add_argument("--stub-engine", action="store_true",
                     help="TEST ONLY: no GPU, no library -- a stand-in engine with made-up statistics, so that the "
@@ -170,6 +171,8 @@ def main(argv=None) -> int:
         engine = Engine(pipeline, config, indices, context=ctx, chunk_events=args.chunk_events or None)
         if args.first_batch_chunks >= 0:
             ctx.set_option("first_batch_chunks", args.first_batch_chunks)
+        if args.track_blocks_per_cu is not None:
+            ctx.set_option("track_blocks_per_cu", args.track_blocks_per_cu)
         if args.serial_tracks is not None:
             ctx.set_option("serial_tracks", args.serial_tracks)
     strong = args.global_events > 0

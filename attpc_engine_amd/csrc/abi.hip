@@ -39,7 +39,11 @@ namespace {
 using namespace attpc;
 
 constexpr int MAX_SLOTS = 8;           // scatter chunks per track batch
+#ifdef ATTPC_PHASE_TIMERS
+constexpr int CTRL_WORDS = 64;         // (diagnostic build: + per-wave timers in 40..63)
+#else
 constexpr int CTRL_WORDS = 40;         // u64 control words per scatter launch (scatter.hip: 0..32 used)
+#endif
 constexpr uint32_t LONE_CAPACITY = 65536;
 constexpr int64_t CLOUD_BUDGET_BYTES = 24ll << 30;  // points + labels of one chunk
 constexpr int64_t DELIVER_CHUNK_ROWS = 96ll << 20;  // cloud rows of a chunk whose cloud is delivered (3 GB: ~60 ms of PCIe)
@@ -656,6 +660,11 @@ int32_t enqueue_scatter(attpc_ctx* ctx, int slot, const attpc_event_layout& lay,
   fprintf(stderr, "[attpc flush cycles] to-barrier %llu to-compacted %llu atomics-wait %llu segment %llu select %llu barrier %llu\n", octrl[27], octrl[23], octrl[24], octrl[25], octrl[26], octrl[14]);
   fprintf(stderr, "[attpc ctrl] rows %llu segments %llu failed %llu retried %llu samples %llu\n", octrl[0], octrl[1],
           octrl[4], octrl[5], octrl[7]);
+  fprintf(stderr, "[attpc per-wave wait at the window's last barrier]");
+  for (int w = 0; w < 16; ++w) fprintf(stderr, " %llu", octrl[40 + w]);
+  fprintf(stderr, "\n[attpc staging, even waves]");
+  for (int w = 0; w < 8; ++w) fprintf(stderr, " %llu", octrl[56 + w]);
+  fprintf(stderr, "\n");
 #endif
   return ATTPC_OK;
 }

@@ -71,6 +71,10 @@ namespace ATTPC_SC_CAT(sc_, ATTPC_SC_VARIANT) {
   do {                                                                       \
     if (tid == 0)                                                            \
       for (int k = 0; k < 20; ++k) atomicAdd(&a.out.ctrl[8 + k], ph_acc[k]); \
+    if (lane == 0 && (tid >> 6) < 16) {  /* per wave: wait at the window's last barrier, staging */ \
+      atomicAdd(&a.out.ctrl[40 + (tid >> 6)], ph_acc[4]);                    \
+      if (((tid >> 6) & 1) == 0) atomicAdd(&a.out.ctrl[56 + (tid >> 7)], ph_acc[3]); \
+    }                                                                        \
   } while (0)
 #else
 #define PHASE_DECL
@@ -150,7 +154,7 @@ constexpr int CTRL_DANGER = 32;      // out.ctrl[]: windows given to lone_bucket
 // the window at a time, ten lanes (the mesh lines of constant y) per sequence; MERGE_G entries of every sequence are
 // staged per round
 #ifndef ATTPC_SC_MERGE_EXTRA  // LDS left beside the default kernel's arrays (one workgroup per CU: 160 KiB, two: 80 KiB each)
-#define ATTPC_SC_MERGE_EXTRA (ATTPC_SC_WG_PER_CU == 1 ? 5800 : 1040)
+#define ATTPC_SC_MERGE_EXTRA (ATTPC_SC_WG_PER_CU == 1 ? 5800 : 976)
 #endif
 constexpr int MERGE_SEQ_PER_WAVE = 64 / MESH;
 constexpr int MERGE_NSEQ = N_WAVES * MERGE_SEQ_PER_WAVE;
@@ -246,6 +250,11 @@ struct __align__(16) ScatterShared {
   unsigned long long wg_samples, wg_rows;                 // workgroup totals (thread 0)
   unsigned long long ev_rows;                             // rows of the current event flushed so far (thread 0)
   unsigned long long charge_sum, key_sum;
+  int merge_lead;  // merge variant: steps the window's foremost wave has done (ds_max_u32; wave priorities follow the lag)
+  double long_w[ATTPC_LONG_STEPS];  // merge variant: DetDev::long_weights (an indexed kernel argument is a global load)
+  double sigma_k[2];  // merge variant: 2 D dv and E of sigma_t^2 = 2 D dv t / E, for the lanes that stage (LDS, not registers:
+                      // as loop invariants in vector registers they were spilled, and a reload from scratch memory waits
+                      // for every load under way -- the touches of the next round included)
 };
 
 static_assert(sizeof(ScatterShared) <= (ATTPC_SC_WG_PER_CU == 1 ? 163840 : 81920), "LDS of a CU / of half a CU");
@@ -674,10 +683,12 @@ struct MergeAcc {
   int pad[MESH];     // -1: no accumulator for this pixel
   uint32_t q[MESH];
   int fill;          // wave uniform: runs waiting in the wave's queue
+  int steps;         // wave uniform: steps of this window done
   uint32_t bound;    // >= every q[j]: the sum of the rows' largest pixels since the accumulators last restarted
   __device__ __forceinline__ void reset() {
     hi = MERGE_NO_HI;
     fill = 0;
+    steps = 0;
     bound = 0u;
 #pragma unroll
     for (int j = 0; j < MESH; ++j) {
@@ -812,6 +823,10 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
   }
   if (tid < ATTPC_MAX_SIM) sh.label_of[tid] = (long long)a.layout.indices[tid];
   if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < ATTPC_LONG_STEPS; ++k) sh.long_w[k] = a.det.long_weights[k];
+    sh.sigma_k[0] = 2.0 * a.det.diffusion * a.det.dv;
+    sh.sigma_k[1] = a.det.efield;
     sh.failed = 0; sh.retried = 0; sh.charge_sum = 0ull; sh.key_sum = 0ull; sh.n_keys = 0u;
     sh.row_cur = 0ull; sh.row_end = 0ull; sh.seg_cur = 0ull; sh.seg_end = 0ull; sh.wg_samples = 0ull; sh.wg_rows = 0ull;
   }
@@ -1249,6 +1264,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           const int wave = tid >> 6;
           const MergeStage ms = merge_stage(sh);
           uint2* __restrict__ queue = sh.queue[wave];
+          const uint32_t qbase = (uint32_t)(uintptr_t)queue;  // LDS byte address of the wave's queue
           const char* __restrict__ lut_bytes = reinterpret_cast<const char*>(lut);
           const unsigned int row_pitch = 2u * (unsigned int)(lut_n + 1);
           unsigned int claimed = 0u, diag_trips = 0u;
@@ -1257,15 +1273,18 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           const int i = lane - sub * MESH;
           const bool lane_ok = sub < MERGE_SEQ_PER_WAVE;
           const int slot0 = (wave * MERGE_SEQ_PER_WAVE + min(sub, MERGE_SEQ_PER_WAVE - 1)) * MERGE_G;
-          // the accumulators named in `ends` -> runs in the wave's queue
-          auto emit = [&](uint32_t ends) {
-            const uint32_t n_runs = (uint32_t)__popc(ends);
-            int first = 0, wave_total = 0;
+          // The accumulators whose pad is given in `ended[]` (-1: this one goes on) -> runs in the wave's queue, column by
+          // column: a run's place is the fill + the runs of the columns before it (scalar popcounts) + the lanes below
+          // it in its own column (mbcnt).  Conditions stay lane masks in scalar registers, nothing is turned into 0/1
+          // vector values and back (the per-lane bit fields of the first version cost ~15 instructions a pixel; a
+          // ballot of anything but a comparison costs two -- hence the -1 convention instead of a flag).
+          auto emit = [&](const int (&ended)[MESH]) {
+            int wave_total = 0;
+            unsigned long long mask[MESH];
 #pragma unroll
-            for (int bit = 0; bit < 4; ++bit) {
-              const unsigned long long mk = __ballot((n_runs >> bit) & 1u);
-              first += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u)) << bit;
-              wave_total += (int)__popcll(mk) << bit;
+            for (int j = 0; j < MESH; ++j) {
+              mask[j] = __builtin_amdgcn_ballot_w64(ended[j] >= 0);
+              wave_total += (int)__popcll(mask[j]);
             }
             if (wave_total == 0) return;
             if (m.fill + wave_total > WAVE_QUEUE) {  // no room: the queued runs go to the table first
@@ -1276,22 +1295,36 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
               if (!ok) return;
             }
             if (wave_total <= WAVE_QUEUE) {
-              int e = m.fill + first;
+              const uint32_t fill0 = (uint32_t)__builtin_amdgcn_readfirstlane(m.fill);
+              uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbase) + 8u * fill0;  // scalar: LDS address of the next run
 #pragma unroll
               for (int j = 0; j < MESH; ++j) {
-                const bool put = (ends >> j) & 1u;
-                queue[put ? e : WAVE_QUEUE] = make_uint2(m.hi | (uint32_t)m.pad[j], m.q[j]);  // WAVE_QUEUE = dump slot
-                e += (int)((ends >> j) & 1u);
+                const unsigned long long mk = mask[j];
+                const uint32_t e = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                asm("" : "+s"(at));  // (kept a scalar of its own: folded into the lane's count it costs a vector add)
+                // queue[e] = (key, electrons) on the lanes of mk (the mask goes to exec as it is: a second `if` on the
+                // comparison would be rebuilt from a 0/1 vector value, two instructions a pixel)
+                unsigned long long saved;
+                asm volatile(
+                    "s_mov_b64 %[saved], exec\n"
+                    "s_mov_b64 exec, %[mk]\n"
+                    "ds_write2_b32 %[addr], %[key], %[q] offset1:1\n"
+                    "s_mov_b64 exec, %[saved]\n"
+                    : [saved] "=&s"(saved)
+                    : [mk] "s"(mk), [addr] "v"(8u * e + at), [key] "v"(m.hi | (uint32_t)ended[j]), [q] "v"(m.q[j])
+                    : "memory");
+                at += 8u * (uint32_t)__popcll(mk);
               }
-              m.fill += wave_total;
+              m.fill = (int)fill0 + wave_total;
             } else {  // more runs than the queue holds (every lane changed bucket at once): in passes
               for (int pass0 = 0; pass0 < wave_total && ok; pass0 += WAVE_QUEUE) {
-                int e = first - pass0;
-#pragma unroll
+                int base = -pass0;
+#pragma unroll  // (not rolled: an index that is not a constant would send the accumulators to scratch memory)
                 for (int j = 0; j < MESH; ++j) {
-                  const bool put = ((ends >> j) & 1u) && e >= 0 && e < WAVE_QUEUE;
-                  queue[put ? e : WAVE_QUEUE] = make_uint2(m.hi | (uint32_t)m.pad[j], m.q[j]);
-                  e += (int)((ends >> j) & 1u);
+                  const unsigned long long mk = mask[j];
+                  const int e = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                  if (ended[j] >= 0 && e >= 0 && e < WAVE_QUEUE) queue[e] = make_uint2(m.hi | (uint32_t)ended[j], m.q[j]);
+                  base += (int)__popcll(mk);
                 }
 #ifndef ATTPC_ABL_NOINSERT
                 ok = stream_insert(sh, queue, min(wave_total - pass0, WAVE_QUEUE), false, carry, claimed, diag_trips);
@@ -1305,7 +1338,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             const bool have = lane_ok && tbw >= 0;
             const bool point = (tbw & (1 << 30)) != 0;
             const uint32_t word_hi = ((uint32_t)(tbw & 0x3ff) << 14) | ((uint32_t)((tbw >> 24) & 7) << 24);
-            const double n_el = ms.n[st];
+            const double n_el = have ? ms.n[st] : 0.0;
             const int ix = ms.ix[st][i];
             const uint32_t* __restrict__ iy32 = reinterpret_cast<const uint32_t*>(&ms.iy[st][0]);
             const double2* __restrict__ w2 = reinterpret_cast<const double2*>(&sh.wtab[i * MESH]);
@@ -1359,40 +1392,52 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             // which accumulators end here: another time bucket / nucleus ends all ten, another pad ends one; all ten
             // are ended as well before one of them could pass 2^31 (a pixel adds less than 2^28): the u32 sums cannot wrap
             // (the centre pixel bounds the other nine -- the weights fall off from the centre -- and is below 2^28 here)
-            const bool restart = have && (word_hi != m.hi || m.bound >= 0x70000000u);
-            uint32_t ends = 0u, changed = 0u;
+            // (bitwise on purpose: `&&` / `||` become branches and 0/1 vector values, `&` / `|` stay lane masks)
+            const bool restart = have & ((word_hi != m.hi) | (m.bound >= 0x70000000u));
+            bool chg[MESH];
+            int ended[MESH];
 #pragma unroll
             for (int j = 0; j < MESH; ++j) {
-              const bool chg = have && (restart || pad[j] != m.pad[j]);
-              changed |= chg ? (1u << j) : 0u;
-              ends |= (chg && m.pad[j] >= 0) ? (1u << j) : 0u;
+              chg[j] = have & (restart | (pad[j] != m.pad[j]));
+              ended[j] = chg[j] ? m.pad[j] : -1;
             }
 #ifdef ATTPC_PHASE_TIMERS
-            asm volatile("" ::"v"(ends), "v"(changed));
             PHASE_SYNC;
             PHASE_MARK(9);
 #endif
-            emit(ends);
+            emit(ended);
 #ifdef ATTPC_PHASE_TIMERS
             PHASE_SYNC;
             PHASE_MARK(10);
 #endif
 #pragma unroll
             for (int j = 0; j < MESH; ++j) {
-              const bool chg = (changed >> j) & 1u;
-              m.pad[j] = chg ? pad[j] : m.pad[j];
-              m.q[j] = (chg ? 0u : m.q[j]) + (have ? el[j] : 0u);  // (also where there is no pad: never emitted)
+              m.pad[j] = chg[j] ? pad[j] : m.pad[j];
+              m.q[j] = (chg[j] ? 0u : m.q[j]) + el[j];  // (el = 0 without an entry; also where there is no pad: never emitted)
             }
             // (a row that went straight to the table left no real pad behind: every accumulator restarts after it)
-            m.bound = have ? (slow ? 0u : (restart ? 0u : m.bound) + el[MESH / 2]) : m.bound;
+            m.bound = slow ? 0u : (restart ? 0u : m.bound) + el[MESH / 2];  // (no entry: no restart, el = 0)
             m.hi = have ? word_hi : m.hi;
             ok = ok && !__any(!slow_ok);
+#ifndef ATTPC_ABL_NOPRIO  // (ablation builds only)
+            {
+              // The waves of a window end at one barrier, and the instruction arbiter serves the oldest wave of a SIMD
+              // first: left alone, waves 0-3 reach the barrier 50 k cycles before waves 12-15 and each SIMD ends the
+              // window on a single wave (nothing to hide its latencies behind).  A wave therefore takes a priority
+              // that grows with the steps it lags behind the foremost wave.
+              const int steps = __builtin_amdgcn_readfirstlane(m.steps) + 1;
+              m.steps = steps;
+              if (lane == 0) atomicMax(&sh.merge_lead, steps);
+              const int lag = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&sh.merge_lead)) - steps;
+              if (lag >= 3) __builtin_amdgcn_s_setprio(3);
+              else if (lag == 2) __builtin_amdgcn_s_setprio(2);
+              else if (lag == 1) __builtin_amdgcn_s_setprio(1);
+              else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
           }
           if (last && ok) {  // the window ends: every accumulator becomes a run, the queue and the runs under way drain
-            uint32_t ends = 0u;
-#pragma unroll
-            for (int j = 0; j < MESH; ++j) ends |= m.pad[j] >= 0 ? (1u << j) : 0u;
-            emit(ends);
+            emit(m.pad);
 #ifndef ATTPC_ABL_NOINSERT
             if (ok) ok = stream_insert(sh, queue, m.fill, true, carry, claimed, diag_trips);
 #endif
@@ -1465,6 +1510,34 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             sh.st_tb[slot] = tb_staged;
           }
         };
+        // Merge variant: the same entry -> staging slot, by TWO lanes (the rounds of this variant stage a few entries
+        // per wave with most lanes idle, and staging was a third of the variant's time): both compute sigma_t, lane
+        // `axis` 0 then takes the ten mesh lines of constant x, lane 1 those of constant y.  Same arithmetic per line
+        // as stage_entry() (the range test is made on the whole number instead of the double: v_cvt saturates, so a
+        // floor outside int32 stays outside the table).
+        auto stage_entry_merge = [&](int slot, int axis, double2 xy, double2 tn, int isim, int sl) {
+          const MergeStage ms = merge_stage(sh);
+          const int ns = local_const(n_slices);  // (as a hoisted 0/1 vector value it was spilled: see sigma_k)
+          const int tb = (int)slice_time(a.det, tn.x, sl, ns);  // transporter.py:238
+          const double sigma = sqrt(sh.sigma_k[0] * tn.x / sh.sigma_k[1]);  // :301 (2 D dv t / E, left to right)
+          const double c = axis ? xy.y : xy.x;
+          const bool sane = sigma >= 0.0;  // (a NaN would convert to 0, the middle of the table: sent far outside instead)
+          const double lo = sane ? c - 3.0 * sigma : 1.0e300, hi = sane ? c + 3.0 * sigma : 1.0e300;
+          const double step = (hi - lo) / (double)(MESH - 1);  // numpy.linspace(c - 3 sigma, c + 3 sigma, 10) (:221-227)
+          // x lines are the ones a lane of the rows phase steps through (iy), its own line is a y line (ix): stage_entry()
+          short* __restrict__ out = axis ? &ms.ix[slot][0] : &ms.iy[slot][0];
+          auto line = [&](int i, double v) {
+            const int k = (int)floor(v * 1000.0) - lut_lo;  // position_to_index (:107-118): whole-mm floor
+            out[i] = (short)min((unsigned int)k, (unsigned int)lut_n);  // low edge inclusive, high edge exclusive
+          };
+#pragma unroll 1
+          for (int i = 0; i < MESH - 1; ++i) line(i, (double)i * step + lo);
+          line(MESH - 1, hi);
+          if (axis == 0) {
+            ms.n[slot] = (ns == 1 ? 1.0 : sh.long_w[sl]) * tn.y;  // x 1.0 is exact
+            ms.tb[slot] = tb | (isim << 24) | ((sigma == 0.0) ? (1 << 30) : 0);
+          }
+        };
         if constexpr (MERGE) {
           // The window is mg_perm[win_r0 .. win_r0 + win_n), cut into MERGE_NSEQ sequences of seq_len consecutive
           // entries.  Every WAVE works on its own MERGE_SEQ_PER_WAVE sequences without a workgroup barrier inside the
@@ -1476,7 +1549,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           const int n_rounds = (n_win + MERGE_ROUND - 1) / MERGE_ROUND;
           const int seq_len = n_rounds * MERGE_G;
           constexpr int WAVE_SLOTS = MERGE_SEQ_PER_WAVE * MERGE_G;  // staging slots of one wave
-          static_assert(WAVE_SLOTS <= 64, "one lane per staging slot of the wave");
+          static_assert(WAVE_SLOTS <= 32, "two lanes per staging slot of the wave");
           MergeAcc acc;
           acc.reset();
           InsertCarry carry;
@@ -1484,10 +1557,16 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           bool ok = true;
           // the previous window's flush resets its table slots and reads its slot list (the queues) without a barrier
           // behind it (it counts on the first barrier of the next staging): here the waves start on their own
+          if (tid == 0) sh.merge_lead = 0;
           block_sync();
           for (int r = 0; r < n_rounds && ok; ++r) {  // wave-uniform
-            if (lane < WAVE_SLOTS) {
-              const int slot = (tid >> 6) * WAVE_SLOTS + lane;
+            // (Tried and dropped, profiles/r03_scatter_phases.md: loads that "touch" what the next round will read -- the
+            //  next words of the list, the next records of the arena -- so that the round's two dependent loads hit the
+            //  L2.  Loads return in order: the first wait for a gather is a wait for the touches as well, so they only
+            //  move the miss from the staging to the first step; +3 % kernel time.)
+            if ((lane & 31) < WAVE_SLOTS) {  // lanes 0.. take the x lines of a slot, lanes 32.. its y lines
+              const int axis = lane >> 5;
+              const int slot = (tid >> 6) * WAVE_SLOTS + (lane & 31);
               const int sq = slot / MERGE_G;
               const int rho = sq * seq_len + r * MERGE_G + (slot - sq * MERGE_G);
               if (rho < n_win) {
@@ -1495,19 +1574,19 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const double* rec = arena + (size_t)(uint32_t)raw * 4u;
                 const uint32_t meta = (uint32_t)(raw >> 32);
-                stage_entry(slot, reinterpret_cast<const double2*>(rec)[0], reinterpret_cast<const double2*>(rec)[1],
-                            (int)((meta >> 10) & 7u), (int)((meta >> 13) & 7u), 0);
+                const double2 rec_xy = reinterpret_cast<const double2*>(rec)[0], rec_tn = reinterpret_cast<const double2*>(rec)[1];
+                stage_entry_merge(slot, axis, rec_xy, rec_tn, (int)((meta >> 10) & 7u), (int)((meta >> 13) & 7u));
               } else {
                 // no entry: the lanes of this slot skip the step -- their gathers still run, so the slot's indices
                 // must point into the table ("off the pad plane"), not at whatever the LDS held
                 const MergeStage ms = merge_stage(sh);
-                ms.tb[slot] = -1;
-                ms.n[slot] = 0.0;
-#pragma unroll
-                for (int k = 0; k < MESH; ++k) {
-                  ms.ix[slot][k] = (short)lut_n;
-                  ms.iy[slot][k] = (short)lut_n;
+                if (axis == 0) {
+                  ms.tb[slot] = -1;
+                  ms.n[slot] = 0.0;
                 }
+                short* __restrict__ out = axis ? &ms.ix[slot][0] : &ms.iy[slot][0];
+#pragma unroll
+                for (int k = 0; k < MESH; ++k) out[k] = (short)lut_n;
               }
             }
             // (LDS operations of one wave complete in order: a fence for the compiler is all that is needed between
@@ -1523,6 +1602,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (*reinterpret_cast<volatile int*>(&sh.overflow)) break;  // another wave gave up on this window already
           }
+          __builtin_amdgcn_s_setprio(0);
           if (!ok) sh.overflow = 1;
           if (last_of_batch && !have_next && tid == 0) {
             next_first = take_batch();

@@ -16,7 +16,7 @@ groups=(
 )
 i=0
 for g in "${groups[@]}"; do
-  timeout -k 10 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d "$OUT/m$i" -o run -- python3 bench.py --workload o16aa --events $N --steps 1 --warmup 0 --no-cpu-baseline --no-delivered > "$OUT/m$i.log" 2>&1 || echo "group $i failed (see $OUT/m$i.log)"
+  timeout -k 10 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d "$OUT/m$i" -o run -- python3 bench.py --workload ${WL:-o16aa} --events $N --steps 1 --warmup 0 --no-cpu-baseline --no-delivered > "$OUT/m$i.log" 2>&1 || echo "group $i failed (see $OUT/m$i.log)"
   echo "pass $i done: $g"
   i=$((i+1))
 done

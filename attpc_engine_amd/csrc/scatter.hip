@@ -1117,6 +1117,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
           const int n_rows = n_stage * MESH;
           const int wave = tid >> 6;
           uint2* __restrict__ queue = sh.queue[wave];
+          const uint32_t qbase = (uint32_t)(uintptr_t)queue;  // LDS byte address of the wave's queue
           const char* __restrict__ lut_bytes = reinterpret_cast<const char*>(lut);
           // LUT [x][y] with one extra row and column of -1: index lut_n stands for "off the pad plane",
           // so off-plane pixels, missing rows and rows handled elsewhere need no masks.  A lane holds
@@ -1193,57 +1194,84 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
                 }
               }
             }
-            // merge runs of equal pads: a run's total sits with its last pixel
+            // Merge runs of equal pads: a run's total sits with its last pixel, `ended[j]` = the pad of a run that ends at
+            // pixel j (-1: none ends there, or the run lies off the pad plane: a stretch of -1 adds up to a total nobody
+            // reads).  Conditions stay lane masks in scalar registers (one ballot of a comparison per pixel); the first
+            // version's per-lane bit fields cost twice the instructions (round 3, profiles/r03_scatter_phases.md).
             uint32_t run_q[MESH];
-            uint32_t ends = 0u;  // bit j: pixel j ends a run on a real pad
+            int ended[MESH];
+            unsigned long long mask[MESH];
+            int wave_total = 0;
             {
               uint32_t acc = 0u;
 #pragma unroll
               for (int j = 0; j < MESH; ++j) {
-                acc += pad[j] >= 0 ? el[j] : 0u;
-                const bool last = (j == MESH - 1) || (pad[j < MESH - 1 ? j + 1 : j] != pad[j]);
+                acc += el[j];
                 run_q[j] = acc;
-                ends |= (last && pad[j] >= 0) ? (1u << j) : 0u;
-                acc = last ? 0u : acc;
+                if (j < MESH - 1) {
+                  const bool last = pad[j + 1] != pad[j];
+                  ended[j] = last ? pad[j] : -1;
+                  acc = last ? 0u : acc;
+                } else {
+                  ended[j] = pad[j];
+                }
+                mask[j] = __builtin_amdgcn_ballot_w64(ended[j] >= 0);
+                wave_total += (int)__popcll(mask[j]);
               }
             }
 #ifdef ATTPC_PHASE_TIMERS
-            asm volatile("" ::"v"(ends), "v"(run_q[9]));
+            asm volatile("" ::"v"(ended[0]), "v"(run_q[9]));
             PHASE_SYNC;
             PHASE_MARK(9);
 #endif
-            // queue positions: exclusive prefix of the run counts (0..10, four bits) over the wave from
-            // four ballots and mbcnt -- no cross-lane data movement
-            const uint32_t n_runs = (uint32_t)__popc(ends);
-            int first = 0, wave_total = 0;
-#pragma unroll
-            for (int bit = 0; bit < 4; ++bit) {
-              const unsigned long long m = __ballot((n_runs >> bit) & 1u);
-              first += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << bit;
-              wave_total += (int)__popcll(m) << bit;
-            }
-            for (int pass0 = 0; pass0 < wave_total; pass0 += WAVE_QUEUE) {
-              int e = first - pass0;  // queue position of this lane's next run in this pass
+            if (wave_total <= WAVE_QUEUE) {
+              // queue positions pixel by pixel: the runs of the pixels before (scalar popcounts) + the lanes below in
+              // the pixel's own mask (mbcnt); the mask goes to exec as it is
+              uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbase);  // scalar: LDS address of the next run
 #pragma unroll
               for (int j = 0; j < MESH; ++j) {
-                const bool put = ((ends >> j) & 1u) && e >= 0 && e < WAVE_QUEUE;
-                queue[put ? e : WAVE_QUEUE] = make_uint2(word_hi | (uint32_t)pad[j], run_q[j]);  // WAVE_QUEUE = dump slot
-                e += (int)((ends >> j) & 1u);
+                const unsigned long long mk = mask[j];
+                const uint32_t e = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                asm("" : "+s"(at));  // (kept a scalar of its own: folded into the lane's count it costs a vector add)
+                unsigned long long saved;
+                asm volatile(
+                    "s_mov_b64 %[saved], exec\n"
+                    "s_mov_b64 exec, %[mk]\n"
+                    "ds_write2_b32 %[addr], %[key], %[q] offset1:1\n"
+                    "s_mov_b64 exec, %[saved]\n"
+                    : [saved] "=&s"(saved)
+                    : [mk] "s"(mk), [addr] "v"(8u * e + at), [key] "v"(word_hi | (uint32_t)ended[j]), [q] "v"(run_q[j])
+                    : "memory");
+                at += 8u * (uint32_t)__popcll(mk);
               }
-              const int n_q = min(wave_total - pass0, WAVE_QUEUE);
 #ifdef ATTPC_PHASE_TIMERS
               PHASE_SYNC;
               PHASE_MARK(10);
 #endif
 #ifndef ATTPC_ABL_NOINSERT  // (ablation builds only: how long does the kernel take without the table inserts)
-              ok = stream_insert(sh, queue, n_q, false, carry, claimed, diag_trips);
+              ok = stream_insert(sh, queue, wave_total, false, carry, claimed, diag_trips);
 #endif
-              diag_calls += (unsigned int)(n_q + 63) / 64u;
+              diag_calls += (unsigned int)(wave_total + 63) / 64u;
 #ifdef ATTPC_PHASE_TIMERS
               PHASE_SYNC;
               PHASE_MARK(11);
 #endif
-              if (!ok) break;
+            } else {  // more runs than the queue holds (nearly every pixel on a pad of its own): in passes
+              for (int pass0 = 0; pass0 < wave_total && ok; pass0 += WAVE_QUEUE) {
+                int base = -pass0;
+#pragma unroll
+                for (int j = 0; j < MESH; ++j) {
+                  const unsigned long long mk = mask[j];
+                  const int e = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                  if (ended[j] >= 0 && e >= 0 && e < WAVE_QUEUE) queue[e] = make_uint2(word_hi | (uint32_t)ended[j], run_q[j]);
+                  base += (int)__popcll(mk);
+                }
+                const int n_q = min(wave_total - pass0, WAVE_QUEUE);
+#ifndef ATTPC_ABL_NOINSERT
+                ok = stream_insert(sh, queue, n_q, false, carry, claimed, diag_trips);
+#endif
+                diag_calls += (unsigned int)(n_q + 63) / 64u;
+              }
             }
             ok = ok && !__any(!slow_ok);  // the slow path fails in single lanes
             if (!ok) break;    // table too full: the whole wave stops together
@@ -1467,20 +1495,21 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             sh.st_tb[slot] = tb | (isim << 24);
             return;
           }
-          const double lo_mm = (double)lut_lo, hi_mm = (double)(lut_lo + lut_n);
           // numpy.linspace(c - 3 sigma, c + 3 sigma, 10) (:221-227) and position_to_index
           // (:107-118: whole-mm floor, low edge inclusive, high edge exclusive) per mesh line
-          const double xlo = xy.x - 3.0 * sigma, xhi = xy.x + 3.0 * sigma;
-          const double ylo = xy.y - 3.0 * sigma, yhi = xy.y + 3.0 * sigma;
+          const bool sane = sigma >= 0.0;  // (a NaN would convert to 0, the middle of the table: sent far outside instead)
+          const double xlo = sane ? xy.x - 3.0 * sigma : 1.0e300, xhi = sane ? xy.x + 3.0 * sigma : 1.0e300;
+          const double ylo = sane ? xy.y - 3.0 * sigma : 1.0e300, yhi = sane ? xy.y + 3.0 * sigma : 1.0e300;
           const double sx = (xhi - xlo) / (double)(MESH - 1), sy = (yhi - ylo) / (double)(MESH - 1);
           auto mesh_line = [&](int i) {
             const double x = (i == MESH - 1) ? xhi : (double)i * sx + xlo;
             const double y = (i == MESH - 1) ? yhi : (double)i * sy + ylo;
-            const double fx = floor(x * 1000.0), fy = floor(y * 1000.0);
             // lanes are mesh lines of constant y that step through x: 8 % fewer runs than the other way
-            // round on the AT-TPC pad plane (the weights are symmetric, so the pixels are the same)
-            const short vy = (fx >= lo_mm && fx < hi_mm) ? (short)((int)fx - lut_lo) : (short)lut_n;
-            const short vx = (fy >= lo_mm && fy < hi_mm) ? (short)((int)fy - lut_lo) : (short)lut_n;
+            // round on the AT-TPC pad plane (the weights are symmetric, so the pixels are the same).
+            // The range test is made on the whole number (v_cvt saturates: a floor outside int32 stays outside the
+            // table; unsigned, so below the low edge is above the high one): two instructions instead of five.
+            const short vy = (short)min((unsigned int)((int)floor(x * 1000.0) - lut_lo), (unsigned int)lut_n);
+            const short vx = (short)min((unsigned int)((int)floor(y * 1000.0) - lut_lo), (unsigned int)lut_n);
             if constexpr (MERGE) {
               const MergeStage ms = merge_stage(sh);
               ms.iy[slot][i] = vy;

@@ -674,6 +674,48 @@ __device__ __forceinline__ bool stream_insert(ScatterShared& sh, const uint2* __
 }
 #endif
 
+// Ten runs per lane at most -> the wave's queue: pixel j's run (key, electrons) goes to LDS address `at` + 8 x (lanes
+// below in mask[j]) on the lanes of mask[j]; `at` = scalar address of the queue's next free entry, advanced past the
+// pixels' runs in turn.  The masks go to exec as they are (an `if` on a mask that crossed a branch is rebuilt by the
+// compiler from a 0/1 vector value: two instructions a pixel), five writes between one save and one restore of exec.
+__device__ __forceinline__ void queue_put(uint32_t at, const unsigned long long (&mask)[MESH], uint32_t hi,
+                                          const int (&ended)[MESH], const uint32_t (&q)[MESH]) {
+  uint32_t addr[MESH];
+#pragma unroll
+  for (int j = 0; j < MESH; ++j) {
+    const unsigned long long mk = mask[j];
+    const uint32_t e = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+    asm("" : "+s"(at));  // (kept a scalar of its own: folded into the lane's count it costs a vector add)
+    addr[j] = 8u * e + at;
+    at += 8u * (uint32_t)__popcll(mk);
+  }
+  static_assert(MESH == 10, "two blocks of five writes");
+#pragma unroll
+  for (int b = 0; b < MESH; b += 5) {
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n"
+        "s_mov_b64 exec, %[m0]\n"
+        "ds_write2_b32 %[a0], %[k0], %[q0] offset1:1\n"
+        "s_mov_b64 exec, %[m1]\n"
+        "ds_write2_b32 %[a1], %[k1], %[q1] offset1:1\n"
+        "s_mov_b64 exec, %[m2]\n"
+        "ds_write2_b32 %[a2], %[k2], %[q2] offset1:1\n"
+        "s_mov_b64 exec, %[m3]\n"
+        "ds_write2_b32 %[a3], %[k3], %[q3] offset1:1\n"
+        "s_mov_b64 exec, %[m4]\n"
+        "ds_write2_b32 %[a4], %[k4], %[q4] offset1:1\n"
+        "s_mov_b64 exec, %[saved]\n"
+        : [saved] "=&s"(saved)
+        : [m0] "s"(mask[b]), [m1] "s"(mask[b + 1]), [m2] "s"(mask[b + 2]), [m3] "s"(mask[b + 3]), [m4] "s"(mask[b + 4]),
+          [a0] "v"(addr[b]), [a1] "v"(addr[b + 1]), [a2] "v"(addr[b + 2]), [a3] "v"(addr[b + 3]), [a4] "v"(addr[b + 4]),
+          [k0] "v"(hi | (uint32_t)ended[b]), [k1] "v"(hi | (uint32_t)ended[b + 1]), [k2] "v"(hi | (uint32_t)ended[b + 2]),
+          [k3] "v"(hi | (uint32_t)ended[b + 3]), [k4] "v"(hi | (uint32_t)ended[b + 4]),
+          [q0] "v"(q[b]), [q1] "v"(q[b + 1]), [q2] "v"(q[b + 2]), [q3] "v"(q[b + 3]), [q4] "v"(q[b + 4])
+        : "memory");
+  }
+}
+
 // Merge variant: what a lane carries along its sequence of entries -- ten accumulators (the pad under each of the
 // ten pixels of its mesh line and the electrons gathered on it since the pad last changed) for one time bucket
 // and nucleus (`hi`, the high bits of the key word), and the fill of the wave's queue.
@@ -1226,24 +1268,8 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
 #endif
             if (wave_total <= WAVE_QUEUE) {
               // queue positions pixel by pixel: the runs of the pixels before (scalar popcounts) + the lanes below in
-              // the pixel's own mask (mbcnt); the mask goes to exec as it is
-              uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbase);  // scalar: LDS address of the next run
-#pragma unroll
-              for (int j = 0; j < MESH; ++j) {
-                const unsigned long long mk = mask[j];
-                const uint32_t e = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                asm("" : "+s"(at));  // (kept a scalar of its own: folded into the lane's count it costs a vector add)
-                unsigned long long saved;
-                asm volatile(
-                    "s_mov_b64 %[saved], exec\n"
-                    "s_mov_b64 exec, %[mk]\n"
-                    "ds_write2_b32 %[addr], %[key], %[q] offset1:1\n"
-                    "s_mov_b64 exec, %[saved]\n"
-                    : [saved] "=&s"(saved)
-                    : [mk] "s"(mk), [addr] "v"(8u * e + at), [key] "v"(word_hi | (uint32_t)ended[j]), [q] "v"(run_q[j])
-                    : "memory");
-                at += 8u * (uint32_t)__popcll(mk);
-              }
+              // the pixel's own mask (mbcnt)
+              queue_put((uint32_t)__builtin_amdgcn_readfirstlane((int)qbase), mask, word_hi, ended, run_q);
 #ifdef ATTPC_PHASE_TIMERS
               PHASE_SYNC;
               PHASE_MARK(10);
@@ -1324,25 +1350,7 @@ __global__ __launch_bounds__(SC_THREADS, (SC_THREADS * ATTPC_SC_WG_PER_CU + 255)
             }
             if (wave_total <= WAVE_QUEUE) {
               const uint32_t fill0 = (uint32_t)__builtin_amdgcn_readfirstlane(m.fill);
-              uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbase) + 8u * fill0;  // scalar: LDS address of the next run
-#pragma unroll
-              for (int j = 0; j < MESH; ++j) {
-                const unsigned long long mk = mask[j];
-                const uint32_t e = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                asm("" : "+s"(at));  // (kept a scalar of its own: folded into the lane's count it costs a vector add)
-                // queue[e] = (key, electrons) on the lanes of mk (the mask goes to exec as it is: a second `if` on the
-                // comparison would be rebuilt from a 0/1 vector value, two instructions a pixel)
-                unsigned long long saved;
-                asm volatile(
-                    "s_mov_b64 %[saved], exec\n"
-                    "s_mov_b64 exec, %[mk]\n"
-                    "ds_write2_b32 %[addr], %[key], %[q] offset1:1\n"
-                    "s_mov_b64 exec, %[saved]\n"
-                    : [saved] "=&s"(saved)
-                    : [mk] "s"(mk), [addr] "v"(8u * e + at), [key] "v"(m.hi | (uint32_t)ended[j]), [q] "v"(m.q[j])
-                    : "memory");
-                at += 8u * (uint32_t)__popcll(mk);
-              }
+              queue_put((uint32_t)__builtin_amdgcn_readfirstlane((int)qbase) + 8u * fill0, mask, m.hi, ended, m.q);
               m.fill = (int)fill0 + wave_total;
             } else {  // more runs than the queue holds (every lane changed bucket at once): in passes
               for (int pass0 = 0; pass0 < wave_total && ok; pass0 += WAVE_QUEUE) {

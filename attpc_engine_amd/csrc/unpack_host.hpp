@@ -39,7 +39,8 @@ struct SpyralHostTables {  // what convert_to_spyral (writer.py:61-112) needs be
   double r_max, window_edge, mm_edge, length;
 };
 
-// n_threads <= 0: min(32, half of the hardware threads); short inputs use fewer threads (one per 65 536 / 32 768 rows)
+// n_threads <= 0: min(32, the CPUs the process may use -- affinity mask and control-group quota honoured; half of them on
+// a machine with 64 or more); short inputs use fewer threads (one per 65 536 / 32 768 rows)
 void unpack_rows(const PackedRow* src, int64_t n, double* points, int64_t* labels, int n_threads);
 void unpack_spyral_rows(const SpyralPacked* src, int64_t n, const SpyralHostTables& t, double* rows, int64_t* labels,
                         int n_threads);

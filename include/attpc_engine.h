@@ -227,7 +227,8 @@ ATTPC_API int32_t attpc_sync(attpc_ctx* ctx);
  *                      with a row that does not fit the record falls back to the next wider form;
  *                      0: rows are copied in the reference's dtypes (32 bytes) straight into the caller's arrays.
  *                      Spyral rows: != 0 = 24-byte records (attpc_unpack_spyral_rows)
- *   "unpack_threads"   host threads of that expansion; 0 (default) = min(32, half of the hardware threads)
+ *   "unpack_threads"   host threads of that expansion; 0 (default) = min(32, the CPUs the process may use: affinity
+ *                      mask and control-group quota honoured, half of them on a machine with 64 or more)
  *   "deliver_chunk_events"  events per chunk when clouds are delivered (default 8192: a chunk's copy hides the next
  *                      chunk's scatter and assembly; the first chunk's device work and the last chunk's expansion
  *                      stand alone, so smaller chunks shorten a short call)

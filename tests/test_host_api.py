@@ -337,6 +337,19 @@ def test_tight_transfer_record_unpack_regenerates_the_jitter():
             first_pass = points.copy()
         else:
             np.testing.assert_array_equal(points, first_pass)   # independent of the slicing
+    # the library has two bodies for this loop (eight rows at a time with AVX2 where the CPU has it and the output
+    # arrays sit on 32-byte boundaries, a scalar one otherwise): both orders of alignment give the same bits
+    room = np.full(3 * n + 8, -1.0)
+    lab_room = np.full(n + 8, -1, dtype=np.int64)
+    for shift in range(4):
+        points = room[shift:shift + 3 * n].reshape(n, 3)
+        labels = lab_room[shift:shift + n]
+        points[:] = -1.0
+        rc = lib.attpc_unpack_rows8(packed.ctypes.data_as(C.c_void_p), n, _abi.iptr(offsets, C.c_int64), n_events, seed, first,
+                                    _abi.dptr(points), _abi.iptr(labels, C.c_int64), 3)
+        assert rc == 0
+        np.testing.assert_array_equal(points, first_pass)
+        np.testing.assert_array_equal(labels, label.astype(np.int64))
     bad = offsets.copy()
     bad[-1] += 1
     assert lib.attpc_unpack_rows8(packed.ctypes.data_as(C.c_void_p), n, _abi.iptr(bad, C.c_int64), n_events, seed, first,

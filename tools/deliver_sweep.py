@@ -12,7 +12,7 @@ pipe, cfg, idx = workloads.o16aa()
 ctx = _abi.Context(0)
 eng = Engine(pipe, cfg, idx, context=ctx)
 eng.run(1000000, seed=3)
-for chunk, threads, compact in ((8192, 16, 2), (8192, 32, 2), (8192, 64, 2), (8192, 96, 2), (16384, 32, 2), (16384, 64, 2), (4096, 64, 2), (8192, 32, 1)):
+for chunk, threads, compact in ((8192, 0, 2), (8192, 8, 2), (8192, 16, 2), (8192, 32, 2), (16384, 16, 2), (4096, 16, 2), (8192, 16, 1)):  # 0 = the library's default
     ctx.set_option("deliver_chunk_events", chunk)
     ctx.set_option("unpack_threads", threads)
     ctx.set_option("compact_transfer", compact)

@@ -56,7 +56,16 @@ void unpack_slice(const PackedRow* src, int64_t lo, int64_t hi, double* points, 
   }
 }
 
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+int64_t unpack_spyral_avx2(const SpyralPacked* src, int64_t r, int64_t hi, const SpyralHostTables& t, double* rows, int64_t* labels);
+bool cpu_has_avx2();
+#endif
+
 void unpack_spyral_slice(const SpyralPacked* src, int64_t lo, int64_t hi, SpyralHostTables t, double* rows, int64_t* labels) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+  // four rows at a time where the CPU has AVX2 and the rows can leave as 16-byte streaming stores
+  if (cpu_has_avx2() && (reinterpret_cast<uintptr_t>(rows) & 15u) == 0) lo = unpack_spyral_avx2(src, lo, hi, t, rows, labels);
+#endif
   for (int64_t r = lo; r < hi; ++r) {
     const unsigned long long b = src[r].bits;
     int pad = (int)((b >> SPYRAL_PACK_CHARGE_BITS) & ((1ull << SPYRAL_PACK_PAD_BITS) - 1));
@@ -76,7 +85,76 @@ void unpack_spyral_slice(const SpyralPacked* src, int64_t lo, int64_t hi, Spyral
     nt_store(t.sizes[pad], &row[7]);
     nt_store((long long)(b >> (SPYRAL_PACK_CHARGE_BITS + SPYRAL_PACK_PAD_BITS)), reinterpret_cast<long long*>(&labels[r]));
   }
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__) && !defined(ATTPC_PLAIN_STORES)
+  _mm_sfence();  // streaming stores are weakly ordered: made visible before the thread reports back
+#endif
 }
+
+#ifdef ATTPC_HAVE_AVX2_PATH
+__attribute__((target("avx2"))) inline __m256d to_f64(__m256i x) {  // whole numbers below 2^52 in 64-bit lanes -> f64, exactly
+  const __m256i magic_i = _mm256_set1_epi64x(0x4330000000000000ll);  // 2^52 as bits
+  const __m256d magic_d = _mm256_set1_pd(4503599627370496.0);         // 2^52
+  return _mm256_sub_pd(_mm256_castsi256_pd(_mm256_or_si256(x, magic_i)), magic_d);
+}
+
+// Spyral rows [r, hi), four per step, `rows` 16-byte aligned (numpy's arrays are): the 24-byte records of four rows
+// are taken apart into columns, the columns computed with the operations of unpack_spyral_slice() in its order
+// (bit-identical: tests/test_host_api.py), and every row leaves as four 16-byte streaming stores.  Returns the first row
+// it did not do.
+__attribute__((target("avx2"))) int64_t unpack_spyral_avx2(const SpyralPacked* src, int64_t r, int64_t hi, const SpyralHostTables& t,
+                                                           double* rows, int64_t* labels) {
+  const __m256d r_max = _mm256_set1_pd(t.r_max), top = _mm256_set1_pd(4095.0), edge = _mm256_set1_pd(t.window_edge);
+  const __m256d span = _mm256_set1_pd(t.window_edge - t.mm_edge), length = _mm256_set1_pd(t.length), thousand = _mm256_set1_pd(1000.0);
+  const __m256i m14 = _mm256_set1_epi64x(0x3fff), m45 = _mm256_set1_epi64x((1ll << SPYRAL_PACK_CHARGE_BITS) - 1);
+  const __m256i last_pad = _mm256_set1_epi64x((long long)(t.n_pads - 1));
+  for (; r + 4 <= hi; r += 4) {
+    const double* in = reinterpret_cast<const double*>(src + r);
+    const __m256d a = _mm256_loadu_pd(in), b = _mm256_loadu_pd(in + 4), c = _mm256_loadu_pd(in + 8);
+    // a = tb0 bits0 int0 tb1 | b = bits1 int1 tb2 bits2 | c = int2 tb3 bits3 int3
+    const __m256d TB = _mm256_permute4x64_pd(_mm256_blend_pd(_mm256_blend_pd(a, b, 0x4), c, 0x2), 0x6C);     // tb0 tb3 tb2 tb1 -> 0 3 2 1
+    const __m256d BT = _mm256_permute4x64_pd(_mm256_blend_pd(_mm256_blend_pd(a, b, 0x9), c, 0x4), 0xB1);     // bits1 bits0 bits3 bits2 -> 1 0 3 2
+    const __m256d INT = _mm256_permute4x64_pd(_mm256_blend_pd(_mm256_blend_pd(a, b, 0x2), c, 0x9), 0xC6);    // int2 int1 int0 int3 -> 2 1 0 3
+    const __m256i bits = _mm256_castpd_si256(BT);
+    const __m256i pad = _mm256_min_epu32(_mm256_and_si256(_mm256_srli_epi64(bits, SPYRAL_PACK_CHARGE_BITS), m14), last_pad);
+    const __m256d q = to_f64(_mm256_and_si256(bits, m45));
+    const __m256d amp = _mm256_min_pd(_mm256_mul_pd(r_max, q), top);  // detector/response.py:55-57, clipped at 4095
+    const __m256d z = _mm256_mul_pd(_mm256_mul_pd(_mm256_div_pd(_mm256_sub_pd(edge, TB), span), length), thousand);  // writer.py:103-105
+    const __m256d padf = to_f64(pad);
+    alignas(32) long long pads[4], labs[4];
+    _mm256_store_si256(reinterpret_cast<__m256i*>(pads), pad);
+    _mm256_store_si256(reinterpret_cast<__m256i*>(labs), _mm256_srli_epi64(bits, SPYRAL_PACK_CHARGE_BITS + SPYRAL_PACK_PAD_BITS));
+    const __m256d size = _mm256_set_pd(t.sizes[pads[3]], t.sizes[pads[2]], t.sizes[pads[1]], t.sizes[pads[0]]);
+    const __m256d za02 = _mm256_unpacklo_pd(z, amp), za13 = _mm256_unpackhi_pd(z, amp);        // z0 a0 | z2 a2,  z1 a1 | z3 a3
+    const __m256d ip02 = _mm256_unpacklo_pd(INT, padf), ip13 = _mm256_unpackhi_pd(INT, padf);
+    const __m256d ts02 = _mm256_unpacklo_pd(TB, size), ts13 = _mm256_unpackhi_pd(TB, size);
+    double* out = rows + 8 * r;
+#if defined(ATTPC_PLAIN_STORES)
+#define ATTPC_ST128(p, v) _mm_storeu_pd(p, v)
+#else
+#define ATTPC_ST128(p, v) _mm_stream_pd(p, v)
+#endif
+    ATTPC_ST128(out + 0, _mm_loadu_pd(t.centers + 2 * pads[0]));
+    ATTPC_ST128(out + 2, _mm256_castpd256_pd128(za02));
+    ATTPC_ST128(out + 4, _mm256_castpd256_pd128(ip02));
+    ATTPC_ST128(out + 6, _mm256_castpd256_pd128(ts02));
+    ATTPC_ST128(out + 8, _mm_loadu_pd(t.centers + 2 * pads[1]));
+    ATTPC_ST128(out + 10, _mm256_castpd256_pd128(za13));
+    ATTPC_ST128(out + 12, _mm256_castpd256_pd128(ip13));
+    ATTPC_ST128(out + 14, _mm256_castpd256_pd128(ts13));
+    ATTPC_ST128(out + 16, _mm_loadu_pd(t.centers + 2 * pads[2]));
+    ATTPC_ST128(out + 18, _mm256_extractf128_pd(za02, 1));
+    ATTPC_ST128(out + 20, _mm256_extractf128_pd(ip02, 1));
+    ATTPC_ST128(out + 22, _mm256_extractf128_pd(ts02, 1));
+    ATTPC_ST128(out + 24, _mm_loadu_pd(t.centers + 2 * pads[3]));
+    ATTPC_ST128(out + 26, _mm256_extractf128_pd(za13, 1));
+    ATTPC_ST128(out + 28, _mm256_extractf128_pd(ip13, 1));
+    ATTPC_ST128(out + 30, _mm256_extractf128_pd(ts13, 1));
+#undef ATTPC_ST128
+    for (int k = 0; k < 4; ++k) nt_store(labs[k], reinterpret_cast<long long*>(&labels[r + k]));
+  }
+  return r;
+}
+#endif
 
 // one row of the 8-byte record, event `ev`
 inline void unpack8_row(unsigned long long b, uint64_t seed, uint64_t ev, int64_t r, double* points, int64_t* labels) {
@@ -98,11 +176,6 @@ inline void unpack8_row(unsigned long long b, uint64_t seed, uint64_t ev, int64_
 // The same operations on the same values as unpack8_row(): bit-identical (tests/test_host_api.py).  Returns the first
 // row it did not do.  (The expansion threads of a GPU box share ~16 cores: the scalar loop's ~60 instructions a row were
 // what bounded the delivered rate, not the memory bandwidth -- tools/unpack_rate.py.)
-__attribute__((target("avx2"))) inline __m256d to_f64(__m256i x) {  // whole numbers below 2^52 in 64-bit lanes -> f64, exactly
-  const __m256i magic_i = _mm256_set1_epi64x(0x4330000000000000ll);  // 2^52 as bits
-  const __m256d magic_d = _mm256_set1_pd(4503599627370496.0);         // 2^52
-  return _mm256_sub_pd(_mm256_castsi256_pd(_mm256_or_si256(x, magic_i)), magic_d);
-}
 template <bool STREAM_LABELS>
 __attribute__((target("avx2"))) int64_t unpack8_event_avx2(const unsigned long long* src, int64_t r, int64_t r_end, uint64_t seed,
                                                            uint64_t ev, double* points, int64_t* labels) {

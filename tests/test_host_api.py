@@ -393,6 +393,16 @@ def test_spyral_transfer_record_unpack(golden_dir):
     np.testing.assert_array_equal(rows, want)  # table look-ups, one subtraction / division / two products, one clipped product
     np.testing.assert_array_equal(labels, labels_in.astype(np.int64))
     assert (want[:, 3] == 4095.0).any() and (want[:, 3] < 40.0).any()
+    # the library's two bodies of this loop (four rows at a time with AVX2 when the rows start on a 16-byte boundary,
+    # one row at a time otherwise) give the same bits
+    room = np.empty(8 * n + 2)
+    for shift in (0, 1):
+        rows2 = room[shift:shift + 8 * n].reshape(n, 8)
+        rows2[:] = -1.0
+        rc = lib.attpc_unpack_spyral_rows(packed.ctypes.data_as(C.c_void_p), n, _abi.dptr(centers), _abi.dptr(sizes), len(sizes),
+                                          float(response.max()), 560, 10, 1.0, _abi.dptr(rows2), _abi.iptr(labels, C.c_int64), 1)
+        assert rc == 0
+        np.testing.assert_array_equal(rows2, want)
 
 
 def test_beam_energy_loss_table_vs_direct_call():

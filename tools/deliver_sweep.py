@@ -12,7 +12,10 @@ pipe, cfg, idx = workloads.o16aa()
 ctx = _abi.Context(0)
 eng = Engine(pipe, cfg, idx, context=ctx)
 eng.run(1000000, seed=3)
-for chunk, threads, compact in ((8192, 0, 2), (8192, 8, 2), (8192, 16, 2), (8192, 32, 2), (16384, 16, 2), (4096, 16, 2), (8192, 16, 1)):  # 0 = the library's default
+SWEEP = ((8192, 0, 2), (8192, 8, 2), (8192, 16, 2), (8192, 32, 2), (16384, 16, 2), (4096, 16, 2), (8192, 16, 1))  # 0 = the library's default
+if len(sys.argv) > 2:  # chunk sizes only: python tools/deliver_sweep.py N 2048,4096,...
+    SWEEP = tuple((int(c), 0, 2) for c in sys.argv[2].split(","))
+for chunk, threads, compact in SWEEP:
     ctx.set_option("deliver_chunk_events", chunk)
     ctx.set_option("unpack_threads", threads)
     ctx.set_option("compact_transfer", compact)

@@ -80,8 +80,53 @@ def longitudinal_weights() -> np.ndarray:
     return 1.5 / np.sqrt(2.0 * np.pi) * np.exp(-1.125 * d * d)
 
 
-def build_det_desc(config, nuclei: list, ode_substeps: int = 1, fold_beam: bool = True):
-    """-> (DetDesc, keepalive).  ``nuclei``: species table (objects with Z, A, mass)."""
+# Configure-time tables are pure functions of their inputs and cost milliseconds each (1 409 stopping-power
+# evaluations per species, the whole-mm pad table, the beam-pad fold): a per-event caller of simulate() would rebuild
+# them for every event just to find that nothing changed.  They are therefore memoised per process on the CONTENT of
+# their inputs (the pad grid's cells go through a CRC: 0.2 ms for 559 x 559 cells) and handed out read-only.
+_DEDX_MEMO: dict = {}
+_LUT_MEMO: dict = {}
+
+
+def _memoised_dedx_table(target, nucleus):
+    """-> (table, key).  key is None for a target that cannot be told from another by value (no ``compound_key``)."""
+    compound = getattr(target, "compound_key", None)
+    if compound is None:
+        return sample_dedx_table(target, nucleus), None
+    key = (type(target).__name__, compound, float(getattr(target, "pressure", 0.0) or 0.0), float(target.density),
+           int(nucleus.Z), int(nucleus.A), float(nucleus.mass))
+    table = _DEDX_MEMO.get(key)
+    if table is None:
+        table = sample_dedx_table(target, nucleus)
+        table.setflags(write=False)
+        _DEDX_MEMO[key] = table
+    return table, key
+
+
+def _memoised_pad_lut(pad_grid, edges, fold_beam: bool):
+    """-> (lut, k_min, key): compact_pad_lut (+ fold_beam_pads), memoised on the grid's content."""
+    import zlib
+
+    grid = np.ascontiguousarray(pad_grid)
+    raw = memoryview(grid).cast("B")
+    key = (grid.shape, str(grid.dtype), zlib.crc32(raw), zlib.adler32(raw), tuple(float(v) for v in edges[:3]), bool(fold_beam))
+    hit = _LUT_MEMO.get(key)
+    if hit is None:
+        lut, k_min = compact_pad_lut(pad_grid, edges)
+        if fold_beam:
+            lut = fold_beam_pads(lut)
+        lut = np.ascontiguousarray(lut)
+        lut.setflags(write=False)
+        if len(_LUT_MEMO) >= 16:
+            _LUT_MEMO.clear()
+        hit = _LUT_MEMO[key] = (lut, k_min)
+    return hit[0], hit[1], key
+
+
+def build_det_desc(config, nuclei: list, ode_substeps: int = 1, fold_beam: bool = True, content_keys: list | None = None):
+    """-> (DetDesc, keepalive).  ``nuclei``: species table (objects with Z, A, mass).  ``content_keys``, if given,
+    receives one hashable key per table the descriptor points to (None where a table has no such key): together
+    with the descriptor's scalar fields they name its content without hashing the tables again."""
     if config.pad_grid_edges is None or config.pad_grid is None:
         raise ValueError("Pad grid is not loaded at generate_point_cloud!")  # solver.py:400-401
     if len(nuclei) > _abi.MAX_SPECIES:
@@ -99,10 +144,9 @@ def build_det_desc(config, nuclei: list, ode_substeps: int = 1, fold_beam: bool 
     desc.mpgd_gain = int(det.mpgd_gain)
     desc.micromegas_edge = int(config.elec_params.micromegas_edge)
     desc.windows_edge = int(config.elec_params.windows_edge)
-    lut, k_min = compact_pad_lut(config.pad_grid, config.pad_grid_edges)
-    if fold_beam:
-        lut = fold_beam_pads(lut)
-    lut = np.ascontiguousarray(lut)
+    lut, k_min, lut_key = _memoised_pad_lut(config.pad_grid, config.pad_grid_edges, fold_beam)
+    if content_keys is not None:
+        content_keys.append(lut_key)
     keep.append(lut)
     desc.pad_lut = lut.ctypes.data_as(C.POINTER(C.c_int16))
     desc.lut_n = lut.shape[0]
@@ -115,7 +159,9 @@ def build_det_desc(config, nuclei: list, ode_substeps: int = 1, fold_beam: bool 
     desc.mc_diffusion = 1 if getattr(det, "mc_diffusion", False) else 0
     desc.path_step = float(getattr(det, "path_step", 0.0) or 0.0)
     for i, nuc in enumerate(nuclei):
-        table = sample_dedx_table(det.gas_target, nuc)
+        table, table_key = _memoised_dedx_table(det.gas_target, nuc)
+        if content_keys is not None:
+            content_keys.append(table_key)
         keep.append(table)
         desc.species[i].Z = int(nuc.Z)
         desc.species[i].A = int(nuc.A)

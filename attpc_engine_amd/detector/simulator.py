@@ -56,8 +56,11 @@ def configure_detector(config: Config, species_keys: list[tuple[int, int]], ctx:
     CONTENT of the descriptor (every parameter, the pad look-up table, the stopping-power tables), not on object
     identity: a parameter changed in place on the same Config object is seen."""
     nuclei = [_nuclear_map().get_data(z, a) for (z, a) in species_keys]
-    desc, keep = build_det_desc(config, nuclei, ode_substeps=ode_substeps)
-    token = _digest(desc, keep)
+    keys: list = []
+    desc, keep = build_det_desc(config, nuclei, ode_substeps=ode_substeps, content_keys=keys)
+    # (the tables are memoised on their inputs' content, luts.py: their keys stand for them; a table without a key --
+    #  a target object that cannot be compared by value -- is hashed itself)
+    token = (_digest(desc, [arr for arr, key in zip(keep, keys) if key is None]), tuple(keys))
     if getattr(ctx, "_det_token", None) == token:
         return
     ctx.check(ctx.lib.attpc_det_configure(ctx.handle, desc), "attpc_det_configure")

@@ -427,3 +427,30 @@ def test_beam_energy_loss_table_vs_direct_call():
         err = np.abs(interpolated - direct).max()
         assert err < 1e-7 * pipeline.beam_energy, (name, err)
         assert direct.max() > 0.01 * pipeline.beam_energy  # the beam does lose energy on its way
+
+
+def test_configure_time_tables_are_memoised_on_content():
+    """detector/luts.py: the whole-mm pad table and the stopping-power tables are rebuilt only when their inputs
+    change IN CONTENT (a per-event caller of simulate() would otherwise spend 4 ms per event on them); the descriptor's
+    content keys name them without hashing them again.  Pure host code."""
+    from attpc_engine_amd import workloads
+    from attpc_engine_amd.detector.luts import build_det_desc
+    _, config, _ = workloads.o16aa()
+    nuclei = [nm.get_data(2, 4), nm.get_data(6, 12)]
+    keys_a, keys_b, keys_c = [], [], []
+    desc_a, keep_a = build_det_desc(config, nuclei, content_keys=keys_a)
+    desc_b, keep_b = build_det_desc(config, nuclei, content_keys=keys_b)
+    assert keys_a == keys_b and all(k is not None for k in keys_a)
+    assert all(x is y for x, y in zip(keep_a, keep_b))          # the same arrays, not equal copies
+    assert not keep_a[0].flags.writeable                          # shared: nobody may write into them
+    grid = config.pad_grid.copy()
+    cell = np.argwhere(grid >= 0)[0]
+    old = int(grid[tuple(cell)])
+    config.pad_grid = grid
+    build_det_desc(config, nuclei, content_keys=keys_c)
+    assert keys_c == keys_a                                       # an equal copy of the grid is the same content
+    grid[tuple(cell)] = old + 1 if old + 1 < 10240 else old - 1   # one cell changed in place
+    keys_d: list = []
+    desc_d, keep_d = build_det_desc(config, nuclei, content_keys=keys_d)
+    assert keys_d[0] != keys_a[0] and keys_d[1:] == keys_a[1:]
+    assert keep_d[0] is not keep_a[0] and (np.asarray(keep_d[0]) != np.asarray(keep_a[0])).sum() >= 1

@@ -420,7 +420,7 @@ def cpu_baseline(workload: str, seed: int) -> dict:
     from oracle import pyoracle as orc
     from tests.helpers import Inputs
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores, cpu_note = usable_cpus()
     inp = Inputs(workload, seed=seed)
     probe = 4 * cores
     t0 = time.perf_counter()
@@ -431,7 +431,32 @@ def cpu_baseline(workload: str, seed: int) -> dict:
     orc.sim_batch(inp.kin, inp.det_raw, inp.layout, seed=seed, first=0, n=n, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "events/s", "cores": cores, "kind": "port",
-            "sample": f"{n} events of the same workload (ids 0..{n - 1}, same seed), OpenMP over events, {dt:.1f} s"}
+            "sample": f"{n} events of the same workload (ids 0..{n - 1}, same seed), OpenMP over events, {dt:.1f} s",
+            "host_cpus": cpu_note}
+
+
+def usable_cpus() -> tuple[int, str]:
+    """CPUs this process may really use: the affinity mask cut down to the CPU quota of its control group (a GPU box
+    shows 256 hardware threads and grants a job 16 of them through cpu.max) -- the thread count of the CPU baseline."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{n} in the affinity mask"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            granted = max(1, -(-int(quota) // int(period)))
+            note += f", control-group quota {quota}/{period} = {granted}"
+            n = min(n, granted)
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                granted = max(1, -(-quota // period))
+                note += f", control-group quota {quota}/{period} = {granted}"
+                n = min(n, granted)
+        except (OSError, ValueError):
+            pass
+    return n, note
 
 
 if __name__ == "__main__":

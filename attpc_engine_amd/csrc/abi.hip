@@ -537,8 +537,8 @@ struct ScatterPlan {  // launch geometry of one chunk
 
 ScatterPlan plan_scatter(const attpc_ctx* ctx, uint32_t n) {
   ScatterPlan p;
-  // Kernel variant: "small" (two 512-thread workgroups with 4096-slot tables per CU) is ~6 % faster
-  // for detectors with the usual diffusion; "big" (one 1024-thread workgroup, 8192 slots) holds twice
+  // Kernel variant: "small" (two 512-thread workgroups with 6144-slot tables per CU) is ~6 % faster
+  // for detectors with the usual diffusion; "big" (one 1024-thread workgroup, 12288 slots) holds twice
   // as many keys per time bucket.  Small is used when a sample is expected to touch at most 40 pads at
   // the far end of the drift (default detector: 28; the same estimate as key_estimate() in scatter.hip)
   // and no extension is on.  A time bucket that fits neither table goes through lone_bucket_kernel; a

@@ -42,10 +42,11 @@
 // (3 f64 + i64, the reference's own dtypes) and 32 B per track sample read.
 #include "tracks_args.hpp"
 
-// This file is compiled twice into the library: as it is ("big": one 1024-thread workgroup with an
-// 8192-slot table per CU) and through scatter_small.hip ("small": two 512-thread workgroups with
-// 4096-slot tables per CU, 6 % faster for detectors with the usual diffusion, but a single time bucket
-// with more than 4096 keys does not fit).  The host picks the variant per launch (abi.hip).
+// This file is compiled three times into the library: as it is ("big": one 1024-thread workgroup with a
+// 12 288-slot table per CU), through scatter_small.hip ("small": two 512-thread workgroups with 6 144-slot
+// tables per CU, 6 % faster for detectors with the usual diffusion, but a single time bucket with more keys
+// than its table holds does not fit) and through scatter_wide.hip ("wide": big's geometry with 8 192 slots of
+// u64 sums, for detectors whose sums pass u32).  The host picks the variant per launch (abi.hip).
 #ifndef ATTPC_SC_VARIANT
 #define ATTPC_SC_VARIANT big
 #endif

@@ -1,4 +1,4 @@
-// scatter_small.hip -- the scatter kernel with two 512-thread workgroups per CU (4096-slot tables).
+// scatter_small.hip -- the scatter kernel with two 512-thread workgroups per CU (6144-slot tables).
 // Same source as scatter.hip, other build-time constants; see the note at the top of scatter.hip.
 // (The constants can be overridden on the command line for experiments; abi.hip's
 // ATTPC_SC_SMALL_WGS must then match ATTPC_SC_WG_PER_CU.)

@@ -112,6 +112,7 @@ struct attpc_ctx {
   int opt_deliver_chunk = 8192;    // events per chunk when clouds are delivered (the pipeline's fill and drain time)
   int opt_merge = -1;              // scatter kernel's merge variant: -1 automatic (path-length dE/dx step), 0 never, 1 always
   int opt_first_batch_chunks = 0;  // > 0: the first track batch of a call spans at most this many scatter chunks
+  int opt_track_species_major = 1; // tracks handed out nucleus by nucleus, lightest species first (0: event by event)
   int opt_track_blocks_per_cu = 8; // track_kernel workgroups (256 threads) launched per CU at most
   int opt_serial_tracks = -1;      // -1 automatic (see pick_track_stream), 0 beside the scatter launches, 1 behind them
 
@@ -457,6 +458,18 @@ int32_t launch_tracks(attpc_ctx* ctx, TrackSet& ts, const TrackLaunch& tl) {
     ta.first_event = tl.first_event;
     ta.n_events = tl.n;
     ta.n_tracks = n_tracks;
+    {  // lightest species first (they travel farthest): the kernel's last tracks are then the short ones
+      int order[ATTPC_MAX_SIM];
+      const int n_sim = tl.lay.n_sim;
+      for (int i = 0; i < n_sim; ++i) order[i] = i;
+      auto weight = [&](int isim) -> double {
+        const int sp = tl.lay.species_of_row[tl.lay.indices[isim]];
+        return sp < 0 ? 1.0e30 : (double)ctx->det.Z[sp] * 1.0e6 + ctx->det.mass[sp];  // by charge, then by mass
+      };
+      std::stable_sort(order, order + n_sim, [&](int x, int y) { return weight(x) < weight(y); });
+      for (int i = 0; i < ATTPC_MAX_SIM; ++i) ta.sim_order[i] = (uint8_t)(i < n_sim ? order[i] : 0);
+      if (!ctx->opt_track_species_major || n_sim <= 1) ta.sim_order[0] = 0xffu;
+    }
     HIP_TRY(ctx, hipEventRecord(ts.t0, ctx->stream_t));
     launch_track_kernel(blocks, lds, ctx->stream_t, ta);
     HIP_TRY(ctx, hipGetLastError());
@@ -1356,6 +1369,8 @@ int32_t attpc_set_option(attpc_ctx* ctx, const char* name, int64_t value) {
   } else if (key == "track_blocks_per_cu") {
     if (value < 1 || value > 64) return fail(ctx, ATTPC_E_INVALID, "track_blocks_per_cu must be 1..64");
     ctx->opt_track_blocks_per_cu = (int)value;
+  } else if (key == "track_species_major") {
+    ctx->opt_track_species_major = value != 0;
   } else if (key == "first_batch_chunks") {
     if (value < 0 || value > MAX_SLOTS) return fail(ctx, ATTPC_E_INVALID, "first_batch_chunks must be 0..8");
     ctx->opt_first_batch_chunks = (int)value;

@@ -131,12 +131,21 @@ __global__ __launch_bounds__(TRACK_THREADS, ATTPC_TRACK_MIN_WAVES) void track_ke
       }
     }  // ... to here
     if (!active && !retired) {
-      tid = next_id;
-      if (tid >= a.n_tracks) {
+      if (next_id >= a.n_tracks) {
         retired = true;
       } else {
-        const uint32_t e_local = tid / (uint32_t)a.layout.n_sim;
-        const int isim = (int)(tid - e_local * (uint32_t)a.layout.n_sim);
+        // id -> (event, nucleus): nucleus-major in the host's order (TrackArgs::sim_order), or event-major
+        uint32_t e_local;
+        int isim;
+        if (a.sim_order[0] != 0xffu) {
+          const uint32_t slot = next_id / a.n_events;
+          e_local = next_id - slot * a.n_events;
+          isim = (int)a.sim_order[slot];
+        } else {
+          e_local = next_id / (uint32_t)a.layout.n_sim;
+          isim = (int)(next_id - e_local * (uint32_t)a.layout.n_sim);
+        }
+        tid = e_local * (uint32_t)a.layout.n_sim + (uint32_t)isim;  // the track's place in the tables
         const int row = a.layout.indices[isim];
         const int sp = a.layout.species_of_row[row];
         const bool dead = sp < 0 || (a.kin_status != nullptr && a.kin_status[e_local] != 0);

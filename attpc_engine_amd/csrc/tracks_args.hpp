@@ -16,6 +16,10 @@ struct TrackArgs {
   uint64_t first_event;       // global id of chunk-local event 0
   uint32_t n_events;
   uint32_t n_tracks;          // n_events * n_sim
+  // Order in which the tracks are handed to the lanes: all events' nucleus sim_order[0] first, then sim_order[1], ...
+  // (the host puts the species with the longest tracks first: the lanes run dry on short tracks at the kernel's end).
+  // sim_order[0] == 0xff: event by event, as the tables are laid out.
+  uint8_t sim_order[ATTPC_MAX_SIM];
 };
 
 struct ScatterArgs {

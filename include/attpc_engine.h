@@ -236,6 +236,9 @@ ATTPC_API int32_t attpc_sync(attpc_ctx* ctx);
  *                      current batch's scatter launches; 0: beside them on a low-priority stream; -1 (default):
  *                      behind on the reference's time grid (beside is 3 % slower there: both kernels are issue
  *                      bound), beside with the path-length dE/dx step (12 % faster there)
+ *   "track_species_major"  1 (default): the track kernel takes its tracks nucleus by nucleus, lightest species first
+ *                      (its lanes then run dry on the short tracks of the heavy ions); 0: event by event.  Scheduling
+ *                      only: results do not depend on it
  *   "first_batch_chunks"  > 0: the first track batch of a call spans at most this many scatter chunks (experiment)
  *   "scatter_merge"    -1 (default) = automatic, 0 = never, 1 = always use the scatter kernel's merge variant, which adds
  *                      up the pixel charges of consecutive track samples that fall on the same pad in the same time

@@ -681,8 +681,10 @@ def test_sums_beyond_u32_switch_to_the_wide_table(orc):
 
 
 def test_scheduling_options_do_not_change_results():
-    """Where the next batch's tracks run (behind / beside the scatter launches: `serial_tracks`) and how long a call's
-    first track batch is (`first_batch_chunks`) are scheduling choices: same checksums for every setting."""
+    """Where the next batch's tracks run (behind / beside the scatter launches: `serial_tracks`), how long a call's
+    first track batch is (`first_batch_chunks`) and in which order the track kernel takes its tracks
+    (`track_species_major`: nucleus by nucleus, lightest species first, or event by event) are scheduling choices: same
+    checksums for every setting."""
     fresh = _abi.Context(0)
     try:
         eng = _engine(Inputs("o16aa"), fresh, chunk_events=1024)
@@ -692,6 +694,11 @@ def test_scheduling_options_do_not_change_results():
                 fresh.set_option("serial_tracks", serial)
                 fresh.set_option("first_batch_chunks", first)
                 got[serial, first] = eng.run(20_000, seed=9, first_event=5)["stats"]
+        fresh.set_option("serial_tracks", -1)
+        fresh.set_option("first_batch_chunks", 0)
+        fresh.set_option("track_species_major", 0)
+        got["event by event", 0] = eng.run(20_000, seed=9, first_event=5)["stats"]
+        fresh.set_option("track_species_major", 1)
         base = got[-1, 0]
         assert base["n_points"] > 0 and base["launches_tracks"] >= 2
         for key, st in got.items():

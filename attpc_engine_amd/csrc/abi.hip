@@ -1139,15 +1139,25 @@ int32_t run_events(attpc_ctx* ctx, uint64_t seed, uint64_t first_event, uint64_t
   // batches of up to MAX_SLOTS chunks (a small pilot batch while the arena need per track is unknown),
   // each integrated on T while the previous batch is scattered on S
   uint64_t b0 = 0;
-  int cur = 0;
+  // the call starts on the track set with the larger buffers: a context's first call leaves set 0 sized for its pilot
+  // batch and set 1 for a full one, and a later call of one batch per call would grow set 0 (arena and all) to the
+  // same size for nothing
+  int cur = ctx->tset[1].p4.bytes > ctx->tset[0].p4.bytes ? 1 : 0;
   TrackLaunch tl[2];
   auto batch_size = [&](uint64_t at) -> uint32_t {
     const uint64_t chunk = (uint64_t)std::max(1, ctx->chunk_events);
     uint64_t want = track_batch_events(ctx, lay, chunk);
-    if (ctx->blocks_per_track <= 0.0) want = std::min<uint64_t>(want, std::min<uint64_t>(chunk, 16384));  // pilot: sizes the arena
-    // the first batch of a call is integrated with nothing to run beside: a shorter one (opt_first_batch_chunks scatter
-    // chunks) leaves less of the call's track time exposed
-    else if (at == 0 && ctx->opt_first_batch_chunks > 0) want = std::min<uint64_t>(want, chunk * (uint64_t)ctx->opt_first_batch_chunks);
+    if (ctx->blocks_per_track <= 0.0) {
+      want = std::min<uint64_t>(want, std::min<uint64_t>(chunk, 16384));  // pilot: sizes the arena
+    } else {
+      // the per-batch buffers -- the sample arena: tens of GB -- are sized for the largest batch a call of this length
+      // has, not for what is left of THIS call behind its pilot batch: the next call of the same length would grow
+      // them all again (8 re-allocations inside a caller's timed region)
+      ctx->max_batch_events = std::max<uint32_t>(ctx->max_batch_events, (uint32_t)std::min<uint64_t>(want, n_events));
+      // the first batch of a call is integrated with nothing to run beside: a shorter one (opt_first_batch_chunks
+      // scatter chunks) leaves less of the call's track time exposed
+      if (at == 0 && ctx->opt_first_batch_chunks > 0) want = std::min<uint64_t>(want, chunk * (uint64_t)ctx->opt_first_batch_chunks);
+    }
     return (uint32_t)std::min<uint64_t>(want, n_events - at);
   };
   // the caller's announcement of the call AFTER this one (attpc_sim_hint_next) belongs to this run alone

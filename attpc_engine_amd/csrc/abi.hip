@@ -199,6 +199,10 @@ int32_t fail(attpc_ctx* ctx, int32_t code, const char* fmt, ...) {
 int32_t ensure(attpc_ctx* ctx, DevBuf& b, size_t bytes) {
   if (bytes <= b.bytes) return ATTPC_OK;
   ctx->n_growths++;
+#ifdef ATTPC_DEBUG_GROWTH  // (diagnostic builds only, tools/build_variant.sh: which buffer is re-allocated, and when)
+  fprintf(stderr, "[attpc grow] buffer at +%zu of the context: %zu -> %zu bytes\n",
+          (size_t)(reinterpret_cast<const char*>(&b) - reinterpret_cast<const char*>(ctx)), b.bytes, bytes);
+#endif
   if (b.p) HIP_TRY(ctx, hipFree(b.p));
   ctx->device_bytes -= b.bytes;
   b.p = nullptr;
@@ -584,7 +588,9 @@ ScatterPlan plan_scatter(const attpc_ctx* ctx, uint32_t n) {
   p.grow_rows = (int64_t)((double)n * known * 1.25) + hole_rows + 65536;
   const double segs = ctx->segs_per_event > 0.0 ? ctx->segs_per_event : 5.0;
   p.need_segs = (int64_t)((double)n * (segs * 1.05 + 0.5)) + 4096 + (int64_t)p.wgs * 16;
-  p.grow_segs = (int64_t)((double)n * (segs * 1.5 + 1.0)) + 4096 + (int64_t)p.wgs * 16;
+  // (24 bytes a segment: when the list has to grow it is sized for a full chunk at once -- a call's chunks are not all
+  //  of one length, and the next call's would re-allocate it inside a caller's timed region)
+  p.grow_segs = (int64_t)((double)std::max<uint32_t>(n, (uint32_t)std::max(1, ctx->chunk_events)) * (segs * 1.5 + 1.0)) + 4096 + (int64_t)p.wgs * 16;
   if (ctx->opt_tiny && ctx->cloud_capacity == 0) {
     p.need_rows = p.grow_rows = 64;  // test hook: start with buffers that are certainly too small
     p.need_segs = p.grow_segs = 2;
